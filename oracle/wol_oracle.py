@@ -1,0 +1,182 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front end of the CPU oracle (oracle/wol_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (waterorderlib_amd) never does: it fails loudly if its HIP library is
+missing instead of falling back to anything here.
+
+Function names mirror the reference's Python/f2py surface (water_properties.py / waterlib) so
+the parity tests read like calls into the reference.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libwol_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "wol_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libwol_oracle.so"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.wolo_cos_angle3.restype = C.c_double
+        L.wolo_np_sum.restype = C.c_double
+        L.wolo_np_mean.restype = C.c_double
+        L.wolo_np_var.restype = C.c_double
+        L.wolo_cos_angs.restype = C.c_long
+        L.wolo_lsi.restype = C.c_long
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _box(b):
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).reshape(-1)[:3])
+    assert b.size == 3
+    return b
+
+
+# ---- waterlib-level -----------------------------------------------------------------------
+def reimage(pos, refpos, boxl):
+    pos = _d(pos); ref = _d(refpos); box = _box(boxl)
+    out = np.empty_like(pos)
+    lib().wolo_reimage(_p(pos), C.c_int(len(pos)), _p(ref), _p(box), _p(out))
+    return out
+
+
+def nearneighbors(subpos, pos, boxl, lowcut, highcut):
+    sub = _d(subpos); pos = _d(pos); box = _box(boxl)
+    mask = np.zeros((len(sub), len(pos)), dtype=np.int32, order="F")
+    lib().wolo_near_neighbors(_p(sub), C.c_int(len(sub)), _p(pos), C.c_int(len(pos)), _p(box),
+                              C.c_double(lowcut), C.c_double(highcut), mask.ctypes.data_as(_ip))
+    return mask
+
+
+def allnearneighbors(pos, boxl, lowcut, highcut):
+    pos = _d(pos); box = _box(boxl)
+    mask = np.zeros((len(pos), len(pos)), dtype=np.int32, order="F")
+    lib().wolo_all_near_neighbors(_p(pos), C.c_int(len(pos)), _p(box), C.c_double(lowcut),
+                                  C.c_double(highcut), mask.ctypes.data_as(_ip))
+    return mask
+
+
+def tetracosang(refpos, neighpos, boxl):
+    ref = _d(refpos); nb = _d(neighpos).reshape(-1, 3); box = _box(boxl)
+    n = len(nb)
+    out = np.empty((n, n), dtype=np.float64)
+    lib().wolo_tetra_cos_ang(_p(ref), _p(nb), C.c_int(n), _p(box), _p(out))
+    return out
+
+
+def lsidists(refpos, neighpos, boxl):
+    ref = _d(refpos); nb = _d(neighpos).reshape(-1, 3); box = _box(boxl)
+    out = np.empty(len(nb), dtype=np.float64)
+    lib().wolo_lsi_dists(_p(ref), _p(nb), C.c_int(len(nb)), _p(box), _p(out))
+    return out
+
+
+def cosangle3(p1, p2, p3):
+    return lib().wolo_cos_angle3(_p(_d(p1)), _p(_d(p2)), _p(_d(p3)))
+
+
+# ---- water_properties-level ----------------------------------------------------------------
+def getOrderParamq(subPos, Pos, BoxDims, lowCut=0.0, highCut=10.0, full=False, cells=False):
+    """water_properties.getOrderParamq; full=True also returns (nn_idx, nn_dist, ang_deg)."""
+    sub = _d(subPos); pos = _d(Pos); box = _box(BoxDims)
+    ns = len(sub)
+    q = np.zeros(ns)
+    idx = np.full((ns, 4), -1, dtype=np.int32)
+    dist = np.full((ns, 4), np.nan)
+    ang = np.full((ns, 6), np.nan)
+    fn = lib().wolo_order_param_q_cells if cells else lib().wolo_order_param_q
+    rc = fn(_p(sub), C.c_int(ns), _p(pos), C.c_int(len(pos)), _p(box), C.c_double(lowCut),
+            C.c_double(highCut), _p(q), idx.ctypes.data_as(_ip), _p(dist), _p(ang))
+    if rc != 0:
+        raise ValueError("cell-list oracle needs a fully periodic box")
+    return (q, idx, dist, ang) if full else q
+
+
+def getCosAngs(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.413):
+    sub = _d(subPos); pos = _d(Pos); box = _box(BoxDims)
+    ns = len(sub)
+    num = np.zeros(ns)
+    args = (_p(sub), C.c_int(ns), _p(pos), C.c_int(len(pos)), _p(box), C.c_double(lowCut), C.c_double(highCut))
+    total = lib().wolo_cos_angs(*args, None, _p(num))
+    ang = np.empty(total)
+    lib().wolo_cos_angs(*args, _p(ang), _p(num))
+    return ang, num
+
+
+def getLSI(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7):
+    sub = _d(subPos); pos = _d(Pos); box = _box(BoxDims)
+    ns = len(sub)
+    full = np.empty(ns)
+    num = np.zeros(ns)
+    lib().wolo_lsi(_p(sub), C.c_int(ns), _p(pos), C.c_int(len(pos)), _p(box), C.c_double(lowCut),
+                   C.c_double(highCut), _p(full), _p(num))
+    return full[~np.isnan(full)], num
+
+
+# ---- numpy restatements / trajectory reduction ---------------------------------------------
+def np_mean(a):
+    a = _d(a)
+    return lib().wolo_np_mean(_p(a), C.c_long(a.size))
+
+
+def np_var(a):
+    a = _d(a)
+    return lib().wolo_np_var(_p(a), C.c_long(a.size))
+
+
+def np_histogram(a, bins=500, range=(0.0, 1.0)):
+    a = _d(a).reshape(-1)
+    counts = np.zeros(bins, dtype=np.int64)
+    lib().wolo_np_histogram(_p(a), C.c_long(a.size), C.c_int(bins), C.c_double(range[0]),
+                            C.c_double(range[1]), counts.ctypes.data_as(_lp))
+    return counts
+
+
+def dist_histogram(d, binwidth=0.01, nbins=1000):
+    d = _d(d).reshape(-1)
+    counts = np.zeros(nbins, dtype=np.int64)
+    lib().wolo_dist_histogram(_p(d), C.c_long(d.size), C.c_double(binwidth), C.c_int(nbins),
+                              counts.ctypes.data_as(_lp))
+    return counts
+
+
+def tet_order_traj(frames, boxes, lowCut=0.0, highCut=10.0, cells=True, qbins=500, dbins=1000,
+                   dbinwidth=0.01):
+    """Per-trajectory reduction of orderParam_lib.tetOrderCalc over frames[T,N,3], boxes[T,3]:
+    returns (mean[T], var[T], qhist[qbins], dhist[dbins])."""
+    frames = _d(frames); boxes = _d(boxes)
+    T, n, _ = frames.shape
+    mean = np.empty(T); var = np.empty(T)
+    qh = np.zeros(qbins, dtype=np.int64); dh = np.zeros(dbins, dtype=np.int64)
+    lib().wolo_tet_order_traj(_p(frames), _p(boxes), C.c_int(T), C.c_int(n), C.c_double(lowCut),
+                              C.c_double(highCut), C.c_int(1 if cells else 0), _p(mean), _p(var),
+                              qh.ctypes.data_as(_lp), C.c_int(qbins), dh.ctypes.data_as(_lp),
+                              C.c_int(dbins), C.c_double(dbinwidth))
+    return mean, var, qh, dh
