@@ -1,0 +1,127 @@
+/*
+ * wol.h -- C ABI of libwol.so, the MI355X (gfx950) implementation of WaterOrderLib's per-frame
+ * water order-parameter hot path.  This is the drop-in boundary: every entry point below is what
+ * the reference's FFI for this path binds (the f2py module `waterlib`, generated from
+ * fortran/waterlib.f90 by fortran/buildWrappers.sh:3-5) or what its per-frame Python loop
+ * (structureLibs/water_properties.py) would call once the per-water work is moved off the host.
+ * The reference-side binding a maintainer adds is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an int status (WOL_OK == 0, <0 = error) and
+ *     never aborts the process (the reference's Fortran `stop`s, e.g. waterlib.f90:22-25);
+ *     wol_last_error() returns the message of the calling thread's last failure.
+ *   - positions are row-major [n][3] doubles (what the Python callers hold: `pos[watInds]`,
+ *     orderParam_lib.py:1462); a row stride (in doubles, >= 3) lets the library read O rows
+ *     straight out of an interleaved [natoms][3] frame (stride = 3*lenWat, TrajObject.py:35-52)
+ *     without the host-side gather.
+ *   - `box` is the three orthorhombic box lengths (frame.box.values[:3], orderParam_lib.py:1461)
+ *     and is ALWAYS a host pointer.  BoxL < 0 marks a non-periodic axis (iBoxL = 0,
+ *     waterlib.f90:41).
+ *   - `mem` says where the bulk arrays (positions and outputs) live: WOL_MEM_HOST (the library
+ *     stages them) or WOL_MEM_DEVICE (HIP device pointers, e.g. torch tensors' data_ptr(); work is
+ *     enqueued on the context's stream and the call returns without synchronising).
+ *   - masks are int32, Fortran order, exactly what f2py returns for a `logical` array.
+ *   - a context is bound to one device and is not thread-safe: one context per host thread/GPU.
+ */
+#ifndef WOL_H
+#define WOL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WOL_OK 0
+#define WOL_ERR_INVALID (-1)  /* bad argument (shape, stride, NULL) */
+#define WOL_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define WOL_ERR_NOMEM (-3)    /* device or host allocation failed */
+#define WOL_ERR_NODEVICE (-4) /* no usable GPU */
+
+#define WOL_MEM_HOST 0
+#define WOL_MEM_DEVICE 1
+
+typedef struct wol_ctx wol_ctx;
+
+int wol_version(void);
+const char* wol_last_error(void);
+
+/* context: device ordinal; owns the stream (unless one is set), workspace and staging buffers */
+int wol_ctx_create(int device, wol_ctx** out);
+int wol_ctx_destroy(wol_ctx* ctx);
+/* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int wol_ctx_set_stream(wol_ctx* ctx, void* hip_stream);
+int wol_ctx_synchronize(wol_ctx* ctx);
+/* tunables: "cell_width" (A, default 5.0), "frames_per_batch", "path" (0 auto, 1 force brute-force,
+ * 2 force exact cell kernel, 3 force filtered cell kernel), "time_kernels" (0/1) */
+int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
+/* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
+ * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
+int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int reset);
+
+/* ---- level 1: the f2py `waterlib` routines on the path (host pointers) -------------------- */
+/* waterlib.f90:32-47 reimage(Pos,RefPos,BoxL) -> ReimagedPos(NPos,3); pos/out row-major [n][3] */
+int wol_reimage(wol_ctx* ctx, const double* pos, int n, const double* refpos, const double* box,
+                double* out);
+/* waterlib.f90:710-743 nearNeighbors -> logical(NsubPos,NPos) as int32 Fortran order */
+int wol_near_neighbors(wol_ctx* ctx, const double* sub, int ns, const double* pos, int n,
+                       const double* box, double lowcut, double highcut, int32_t* mask);
+/* waterlib.f90:830-862 allNearNeighbors -> logical(NPos,NPos) */
+int wol_all_near_neighbors(wol_ctx* ctx, const double* pos, int n, const double* box, double lowcut,
+                           double highcut, int32_t* mask);
+/* waterlib.f90:867-895 tetraCosAng -> allAngs(n,n), degrees, symmetric; the diagonal (left
+ * uninitialised by the reference) is written as 0 */
+int wol_tetra_cos_ang(wol_ctx* ctx, const double* refpos, const double* neigh, int n,
+                      const double* box, double* allangs);
+/* waterlib.f90:900-918 lsiDists -> dist(n) */
+int wol_lsi_dists(wol_ctx* ctx, const double* refpos, const double* neigh, int n, const double* box,
+                  double* dist);
+
+/* ---- level 2: one frame of water_properties.py ------------------------------------------- */
+/* getOrderParamq (water_properties.py:344-391), fused: minimum-image neighbour search, 4-NN
+ * selection, six angles, q.  sub == NULL means sub is pos (the allnearneighbors branch, wp:363).
+ * Outputs (q required, others nullable):
+ *   q[ns]; nn_idx[ns][4] global index into pos, -1 padded; nn_dist[ns][4] ascending, NaN padded;
+ *   ang_deg[ns][6] the six angles that enter q (180 padded as wp:379-384, NaN if no neighbour). */
+int wol_q_frame(wol_ctx* ctx, const double* pos, int64_t pos_stride, int n, const double* sub,
+                int64_t sub_stride, int ns, const double* box, double lowcut, double highcut,
+                double* q, int32_t* nn_idx, double* nn_dist, double* ang_deg, int mem);
+
+/* getCosAngs (water_properties.py:210-250): all k(k-1)/2 angles per water over the shell
+ * lowcut < d <= highcut, flattened in water order.  Two calls: with ang == NULL it fills
+ * num_angs[ns] (= k per water, as a double like the reference's np.zeros) and *total; then with a
+ * buffer of *total doubles.  Host pointers. */
+int wol_cos_angs(wol_ctx* ctx, const double* pos, int n, const double* sub, int ns,
+                 const double* box, double lowcut, double highcut, double* ang, double* num_angs,
+                 int64_t* total);
+
+/* getLSI (water_properties.py:252-311): lsi_full[ns] = LSI of water i or NaN where the reference
+ * skips the water; num_lsi[ns] as wp:306; *nvalid = len(lsiVals).  Host pointers. */
+int wol_lsi_frame(wol_ctx* ctx, const double* pos, int n, const double* sub, int ns,
+                  const double* box, double lowcut, double highcut, double* lsi_full,
+                  double* num_lsi, int64_t* nvalid);
+
+/* ---- level 3: the tetOrderCalc frame loop (orderParam_lib.py:1458-1495) ------------------- */
+/* T frames of n waters each; water w of frame t is at frames + t*frame_stride + w*atom_stride
+ * (strides in doubles).  boxes is host [T][3].  Per frame: q for every water (sub == pos branch),
+ * np.mean/np.var (mean[T], var[T]); over all frames: np.histogram(q, qbins, [0,1]) counts added
+ * into qhist[qbins] and the sorted 4-NN O-O distances binned by the reference's pair-histogram
+ * rule nbin = ceiling(d/binwidth) (waterlib.f90:219-222) added into dhist[dbins].  Histograms are
+ * ACCUMULATED (caller zeroes them) so frame shards and ranks can be summed.  q_out (nullable)
+ * receives q[T][n].  Any of mean/var/qhist/dhist/q_out may be NULL. */
+int wol_q_traj(wol_ctx* ctx, const double* frames, int64_t atom_stride, int64_t frame_stride, int T,
+               int n, const double* boxes, double lowcut, double highcut, double* mean, double* var,
+               int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth,
+               double* q_out, int mem);
+
+/* same with float32 storage (BASELINE config 5): coordinates are promoted to double exactly, the
+ * arithmetic is the fp64 path's, q_out is rounded to float */
+int wol_q_traj_f32(wol_ctx* ctx, const float* frames, int64_t atom_stride, int64_t frame_stride,
+                   int T, int n, const double* boxes, double lowcut, double highcut, double* mean,
+                   double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,
+                   double dbinwidth, float* q_out, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WOL_H */

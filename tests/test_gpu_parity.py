@@ -1,0 +1,177 @@
+"""GPU parity tests proper: the HIP path (through the C ABI, via the reference-style Python
+surface) against (i) the golden vectors the reference produced and (ii) the CPU oracle on seeded
+inputs.  Bars (BASELINE.json north_star): neighbour indices bit-exact; q and angles within 1e-6
+(fp64) -- asserted far tighter here (1e-9 deg on angles, 1e-12 on q) because only libm-level
+differences (acos/cos) are expected; distances and integer histograms bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import Q_CASES, case_inputs, golden
+
+pytestmark = pytest.mark.gpu
+
+ANG_TOL = 1e-9   # degrees
+Q_TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def wp():
+    from waterorderlib_amd import water_properties
+    return water_properties
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    """one context per search path: 0 auto, 1 all-pairs, 2 exact cell list"""
+    from waterorderlib_amd import _lib
+    out = {}
+    for path in (0, 1, 2):
+        c = _lib.Context(0)
+        c.set_option("path", path)
+        out[path] = c
+    yield out
+    for c in out.values():
+        c.close()
+
+
+def check_full(res, g_q, g_idx, g_dist, g_ang):
+    q, idx, dist, ang = res
+    assert np.array_equal(idx, g_idx), "neighbour indices differ"
+    assert np.array_equal(dist, g_dist, equal_nan=True), "neighbour distances differ"
+    np.testing.assert_allclose(ang, g_ang, rtol=0, atol=ANG_TOL, equal_nan=True)
+    np.testing.assert_allclose(q, g_q, rtol=0, atol=Q_TOL)
+
+
+@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("name", Q_CASES)
+def test_q_golden(wp, ctxs, name, path):
+    g = golden(name)
+    sub, pos, box, lo, hi = case_inputs(g)
+    res = wp.getOrderParamq(sub, pos, box, lo, hi, full=True, ctx=ctxs[path])
+    check_full(res, g["q"], g["nn_idx"], g["nn_dist"], g["ang"])
+    # plain call returns q only, like the reference
+    q = wp.getOrderParamq(sub, pos, box, lo, hi, ctx=ctxs[path])
+    assert q.shape == (len(sub),) and np.array_equal(q, res[0])
+
+
+@pytest.mark.parametrize("path", [1, 2])
+@pytest.mark.parametrize("n,seed,cw", [(3000, 21, 5.0), (3000, 22, 3.1), (10000, 23, 5.0), (4097, 24, 7.7)])
+def test_q_vs_oracle(wp, ctxs, oracle, n, seed, cw, path):
+    from waterorderlib_amd import synth
+    xyz, boxes = synth.water_frames(n, 1, seed=seed)
+    pos, box = xyz[0], boxes[0]
+    ctxs[path].set_option("cell_width", cw)
+    res = wp.getOrderParamq(pos, pos, box, full=True, ctx=ctxs[path])
+    ctxs[path].set_option("cell_width", 5.0)
+    ref = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    check_full(res, *ref)
+
+
+def test_q_gas_and_subsets_vs_oracle(wp, ctxs, oracle):
+    from waterorderlib_amd import synth
+    pos, box = synth.ideal_gas(6000, seed=31)
+    box = box * np.array([1.0, 1.3, 0.8])
+    pos = pos * np.array([1.0, 1.3, 0.8])
+    ref = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    check_full(wp.getOrderParamq(pos, pos, box, full=True, ctx=ctxs[2]), *ref)
+    # sub-population branch through the cell path: rows of pos and arbitrary points
+    rng = np.random.default_rng(5)
+    rows = pos[rng.choice(len(pos), 700, replace=False)]
+    check_full(wp.getOrderParamq(rows, pos, box, full=True, ctx=ctxs[2]),
+               *oracle.getOrderParamq(rows, pos, box, full=True, cells=True))
+    pts = rng.random((333, 3)) * box * 3.0 - box
+    check_full(wp.getOrderParamq(pts, pos, box, full=True, ctx=ctxs[2]),
+               *oracle.getOrderParamq(pts, pos, box, full=True, cells=True))
+    # short cutoffs: most waters have fewer than four neighbours (180-degree padding, wp:379-384)
+    for lo, hi in ((0.0, 3.0), (2.5, 3.6), (0.0, 17.0)):
+        check_full(wp.getOrderParamq(pos[:2000], pos, box, lo, hi, full=True, ctx=ctxs[2]),
+                   *oracle.getOrderParamq(pos[:2000], pos, box, lo, hi, full=True, cells=True))
+
+
+def test_slab_with_vapour(wp, ctxs, oracle):
+    """BASELINE config 5 geometry at test size: vacuum gap >> cutoff, isolated waters (q = 0)"""
+    from waterorderlib_amd import synth
+    xyz, boxes = synth.slab_frames(4000, 1, seed=41, n_vapour=60)
+    pos, box = xyz[0], boxes[0]
+    ref = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    assert (ref[1][:, 3] < 0).sum() > 0
+    for path in (1, 2):
+        check_full(wp.getOrderParamq(pos, pos, box, full=True, ctx=ctxs[path]), *ref)
+
+
+def test_analytic_and_edge_cases(wp, ctxs):
+    tet = np.array([[1, 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]], float)
+    pos = np.vstack([np.zeros(3), tet * 1.6]) + 15.0
+    q, idx, dist, ang = wp.getOrderParamq(pos[:1], pos, np.array([30.0] * 3), full=True)
+    assert abs(q[0] - 1.0) < 1e-13
+    np.testing.assert_allclose(ang[0], np.degrees(np.arccos(-1.0 / 3.0)), atol=1e-9)
+    lone = np.array([[1.0, 2.0, 3.0], [40.0, 40.0, 40.0]])
+    q, idx, dist, ang = wp.getOrderParamq(lone, lone, np.array([90.0] * 3), full=True)
+    assert np.all(q == 0.0) and np.all(idx == -1) and np.all(np.isnan(dist)) and np.all(np.isnan(ang))
+    pair = np.array([[1.0, 2.0, 3.0], [2.0, 2.0, 3.0]])
+    q, idx, dist, ang = wp.getOrderParamq(pair, pair, np.array([90.0] * 3), full=True)
+    assert np.all(ang == 180.0) and np.all(np.abs(q) < 1e-15) and idx[0, 0] == 1 and idx[1, 0] == 0
+    # empty inputs
+    assert wp.getOrderParamq(np.zeros((0, 3)), pos, np.array([30.0] * 3)).shape == (0,)
+    q = wp.getOrderParamq(pos, np.zeros((0, 3)), np.array([30.0] * 3))
+    assert q.shape == (5,) and np.all(q == 0.0)
+    # BoxDims of shape (1,3) is accepted like f2py does
+    q2 = wp.getOrderParamq(pos[:1], pos, np.array([[30.0, 30.0, 30.0]]))
+    assert abs(q2[0] - 1.0) < 1e-13
+    with pytest.raises(ValueError):
+        wp.getOrderParamq(np.zeros((4, 2)), pos, np.array([30.0] * 3))
+
+
+def test_waterlib_level1(oracle):
+    import waterorderlib_amd.waterlib as wl
+    g = golden("waterlib_kat")
+    ang = wl.tetracosang(g["tet_pos"][0], g["tet_pos"][1:], g["tet_box"])
+    assert ang.flags.f_contiguous
+    np.testing.assert_allclose(ang[np.triu_indices(4, k=1)], g["tet_ang"], rtol=0, atol=ANG_TOL)
+    assert np.array_equal(wl.reimage(g["reimage_in"], np.zeros(3), np.array([10.0] * 3)), g["reimage_out"])
+    assert np.array_equal(wl.lsidists(g["tet_pos"][0], g["tet_pos"][1:] + 40.0, g["tet_box"]), g["lsidists"])
+    for name in ("gas512", "tiny_box", "nonperiodic_z", "subpop_points", "cut_2p9_4p0"):
+        gg = golden(name)
+        sub, pos, box, lo, hi = case_inputs(gg)
+        m = wl.nearneighbors(sub, pos, box, lo, hi)
+        assert m.dtype == np.int32 and m.flags.f_contiguous and m.shape == (len(sub), len(pos))
+        assert np.array_equal(m, oracle.nearneighbors(sub, pos, box, lo, hi))
+        assert int(m.sum()) == int(gg["mask_sum"])
+        if "sub" not in gg.files:
+            assert np.array_equal(wl.allnearneighbors(pos, box, lo, hi), m)
+
+
+def test_traj_golden_and_oracle(oracle):
+    from waterorderlib_amd import engine, synth
+    g = golden("traj700x3")
+    res = engine.tet_order_traj(g["frames"], g["boxes"], want_q=True)
+    np.testing.assert_allclose(res.q, g["q"], rtol=0, atol=Q_TOL)
+    np.testing.assert_allclose(res.mean, g["mean"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(res.var, g["var"], rtol=0, atol=1e-13)
+    assert np.array_equal(res.qhist, g["qhist"])
+    # a bigger batch against the oracle (cell path, several frames per launch, TIP4P-style frames)
+    xyz, boxes = synth.water_frames(5000, 12, seed=77, len_wat=4)
+    res = engine.tet_order_traj(xyz, boxes, len_wat=4, want_q=True)
+    mean, var, qh, dh = oracle.tet_order_traj(np.ascontiguousarray(xyz[:, 0::4]), boxes)
+    np.testing.assert_allclose(res.mean, mean, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(res.var, var, rtol=0, atol=1e-13)
+    assert np.array_equal(res.qhist, qh) and np.array_equal(res.dhist, dh)
+    assert res.dhist.sum() == 4 * 5000 * 12
+
+
+def test_traj_device_resident_matches_host():
+    import torch
+    from waterorderlib_amd import engine, synth
+    xyz, boxes = synth.water_frames(6000, 16, seed=78)
+    host = engine.tet_order_traj(xyz, boxes, want_q=True)
+    dev = engine.tet_order_traj(torch.from_numpy(xyz).cuda(), boxes, want_q=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.q.cpu().numpy(), host.q)
+    assert np.array_equal(dev.mean.cpu().numpy(), host.mean) and np.array_equal(dev.var.cpu().numpy(), host.var)
+    assert np.array_equal(dev.qhist.cpu().numpy(), host.qhist) and np.array_equal(dev.dhist.cpu().numpy(), host.dhist)
+    # float32 storage: coordinates promoted exactly, same arithmetic => equals fp64 run on the rounded frames
+    x32 = xyz.astype(np.float32)
+    a = engine.tet_order_traj(x32, boxes, want_q=True)
+    b = engine.tet_order_traj(x32.astype(np.float64), boxes, want_q=True)
+    assert np.array_equal(a.qhist, b.qhist) and np.array_equal(a.dhist, b.dhist)
+    assert np.array_equal(a.mean, b.mean) and np.array_equal(a.q, b.q.astype(np.float32))

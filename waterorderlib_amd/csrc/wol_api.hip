@@ -1,0 +1,660 @@
+// wol_api.hip -- host side of libwol.so: the C ABI declared in include/wol.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared wol_api.hip -o libwol.so
+#include "wol_kernels.hip"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wol.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? WOL_ERR_NOMEM : WOL_ERR_HIP, "%s: %s",    \
+                        #expr, hipGetErrorString(e_));                                        \
+    } while (0)
+
+#define WOL_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != WOL_OK) return rc_; \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return WOL_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return WOL_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return WOL_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return WOL_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct wol_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // options
+    double cell_width = 5.0;
+    int frames_per_batch = 0;
+    int path = 0;
+    bool time_kernels = false;
+    // workspace
+    DevBuf sorted, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small;
+    PinBuf grids_host;
+    hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
+    bool grid_copy_pending = false;
+    // dominant-kernel timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
+    double ms_total = 0.0;
+    int64_t launches = 0;
+};
+
+namespace {
+
+Box3 make_box(const double* box) {
+    Box3 b;
+    for (int k = 0; k < 3; ++k) {
+        b.L[k] = box[k];
+        b.ib[k] = (box[k] >= 0.0) ? 1.0 / box[k] : 0.0;  // waterlib.f90:41
+    }
+    return b;
+}
+
+// Builds the uniform grid of one frame.  Returns false when the frame must take the all-pairs
+// path: a non-periodic axis (BoxL < 0), BoxL == 0 or a non-finite length.
+bool make_grid(const double* box, int n, double cell_width, double high, FrameGrid* g) {
+    g->box = make_box(box);
+    g->maxshell = -1;
+    g->ncell = 1;
+    for (int k = 0; k < 3; ++k) { g->nc[k] = 1; g->cw[k] = 1.0; g->lo[k] = g->hi[k] = 0; }
+    for (int k = 0; k < 3; ++k)
+        if (!(box[k] > 0.0) || !std::isfinite(box[k])) return false;
+    if (!(high > 0.0) || !std::isfinite(high)) return false;
+    double w = cell_width > 0.5 ? cell_width : 0.5;
+    const double cap = std::fmax(4.0 * (double)n, 4096.0);
+    for (int iter = 0; iter < 64; ++iter) {
+        double prod = 1.0;
+        for (int k = 0; k < 3; ++k) {
+            double c = std::floor(box[k] / w);
+            if (c < 1.0) c = 1.0;
+            if (c > 1024.0) c = 1024.0;
+            g->nc[k] = (int)c;
+            prod *= c;
+        }
+        if (prod <= cap) break;
+        w *= 1.2;
+    }
+    g->ncell = g->nc[0] * g->nc[1] * g->nc[2];
+    int ms = 0;
+    for (int k = 0; k < 3; ++k) {
+        g->cw[k] = box[k] / g->nc[k];
+        double mk = std::ceil((high + 1e-6) / g->cw[k]);
+        if (mk > 1e6) mk = 1e6;
+        int m = (int)mk;
+        if (2 * m + 1 >= g->nc[k]) { g->lo[k] = (g->nc[k] - 1) / 2; g->hi[k] = g->nc[k] / 2; }
+        else { g->lo[k] = g->hi[k] = m; }
+        ms = std::max(ms, std::max(g->lo[k], g->hi[k]));
+    }
+    g->maxshell = ms;
+    return true;
+}
+
+int begin_timing(wol_ctx* c, std::pair<hipEvent_t, hipEvent_t>* ev) {
+    if (c->ev_free.empty()) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        *ev = {a, b};
+    } else {
+        *ev = c->ev_free.back();
+        c->ev_free.pop_back();
+    }
+    HIP_TRY(hipEventRecord(ev->first, c->stream));
+    return WOL_OK;
+}
+
+int end_timing(wol_ctx* c, const std::pair<hipEvent_t, hipEvent_t>& ev) {
+    HIP_TRY(hipEventRecord(ev.second, c->stream));
+    c->ev_used.push_back(ev);
+    return WOL_OK;
+}
+
+int collect_timing(wol_ctx* c) {
+    if (c->ev_used.empty()) return WOL_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& ev : c->ev_used) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        c->ms_total += ms;
+        c->launches += 1;
+        c->ev_free.push_back(ev);
+    }
+    c->ev_used.clear();
+    return WOL_OK;
+}
+
+struct HistArgs {
+    unsigned long long* qhist = nullptr;  // device
+    unsigned long long* dhist = nullptr;  // device
+    int qbins = 0, dbins = 0;
+    double dbinwidth = 0.0;
+};
+
+// Runs the q pipeline on F device-resident frames (views already point at device memory).
+// out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
+template <typename T>
+int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
+                int64_t sub_stride, int ns, double low, double high, QOut out) {
+    const int n = fv.n;
+    if (F <= 0 || ns <= 0) return WOL_OK;
+    const double lowsq = low * low, highsq = high * high;
+    const size_t hist_lds = (size_t)((out.qhist ? out.qbins : 0) + (out.dhist ? out.dbins : 0)) * sizeof(int);
+
+    // --- per-frame grids (host) ---
+    if (c->grid_copy_pending) {  // the pinned staging buffer is still being read by an earlier upload
+        HIP_TRY(hipEventSynchronize(c->grid_ev));
+        c->grid_copy_pending = false;
+    }
+    WOL_TRY(c->grids_host.ensure(sizeof(FrameGrid) * (size_t)F));
+    FrameGrid* gh = c->grids_host.as<FrameGrid>();
+    int64_t cell_total = 0;
+    int n_cell_frames = 0;
+    std::vector<int> brute_frames;
+    const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
+    for (int f = 0; f < F; ++f) {
+        bool ok = !force_brute && make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f]);
+        if (!ok) {
+            make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f]);
+            gh[f].maxshell = -1;  // search kernel skips this frame
+            gh[f].ncell = 1;
+            for (int k = 0; k < 3; ++k) gh[f].nc[k] = 1;
+            brute_frames.push_back(f);
+        } else {
+            ++n_cell_frames;
+        }
+        gh[f].cell_base = cell_total;
+        cell_total += gh[f].ncell + 1;
+    }
+
+    if (n_cell_frames > 0) {
+        WOL_TRY(c->grids.ensure(sizeof(FrameGrid) * (size_t)F));
+        WOL_TRY(c->cells.ensure(sizeof(int) * (size_t)cell_total));
+        WOL_TRY(c->sorted.ensure(sizeof(double4) * (size_t)F * n));
+        WOL_TRY(c->cellid.ensure(sizeof(int) * (size_t)F * n));
+        WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * n));
+        HIP_TRY(hipMemcpyAsync(c->grids.p, gh, sizeof(FrameGrid) * (size_t)F, hipMemcpyHostToDevice, c->stream));
+        if (!c->grid_ev) HIP_TRY(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
+        c->grid_copy_pending = true;
+        HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)cell_total, c->stream));
+        const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
+        hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
+        hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
+        hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>());
+
+        SearchArgs a;
+        a.grids = c->grids.as<FrameGrid>();
+        a.sorted = c->sorted.as<double4>();
+        a.cell_start = c->cells.as<int>();
+        a.n = n;
+        a.F = F;
+        a.sub = reinterpret_cast<const double*>(sub);  // only double reaches here with sub != null
+        a.sub_stride = sub_stride;
+        a.ns = ns;
+        a.lowsq = lowsq; a.highsq = highsq; a.high = high;
+        a.out = out;
+        a.tiles_per_frame = (ns + WOL_BLOCK - 1) / WOL_BLOCK;
+        a.xcd_affine = (F >= 8) ? 1 : 0;
+        const int64_t total = (int64_t)F * a.tiles_per_frame;
+        int grid = (int)std::min<int64_t>(total, 2048);
+        if (a.xcd_affine) grid = std::max(8, (grid / 8) * 8);
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+        hipLaunchKernelGGL(k_search_exact, dim3(grid), dim3(WOL_BLOCK), hist_lds, c->stream, a);
+        if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    }
+    for (int f : brute_frames) {
+        PointsView<T> pv{fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, n};
+        PointsView<T> sv = sub ? PointsView<T>{sub, sub_stride, ns} : pv;
+        const Box3 b = make_box(boxes_host + 3 * (size_t)f);
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+        hipLaunchKernelGGL(k_brute_q<T>, dim3((ns + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), hist_lds,
+                           c->stream, pv, sv, b, lowsq, highsq, out, (int64_t)f * ns);
+        if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    }
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+int check_ctx(wol_ctx* c) {
+    if (!c) return fail(WOL_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return WOL_OK;
+}
+
+template <typename T>
+int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_stride, int T_frames,
+                int n, const double* boxes, double low, double high, double* mean, double* var,
+                int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, T* q_out, int mem) {
+    WOL_TRY(check_ctx(c));
+    if (!frames || !boxes) return fail(WOL_ERR_INVALID, "frames/boxes must not be NULL");
+    if (T_frames < 0 || n <= 0) return fail(WOL_ERR_INVALID, "need T >= 0 and n > 0 (got T=%d n=%d)", T_frames, n);
+    if (atom_stride < 3) return fail(WOL_ERR_INVALID, "atom_stride must be >= 3");
+    if (frame_stride < (int64_t)(n - 1) * atom_stride + 3 && T_frames > 1)
+        return fail(WOL_ERR_INVALID, "frame_stride smaller than one frame");
+    if (qhist && qbins <= 0) return fail(WOL_ERR_INVALID, "qbins must be > 0");
+    if (dhist && (dbins <= 0 || !(dbinwidth > 0.0))) return fail(WOL_ERR_INVALID, "dbins/dbinwidth must be > 0");
+    if ((qhist ? qbins : 0) + (dhist ? dbins : 0) > 12000) return fail(WOL_ERR_INVALID, "too many histogram bins for LDS");
+    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    if (T_frames == 0) return WOL_OK;
+    const bool host = (mem == WOL_MEM_HOST);
+
+    int Fb = c->frames_per_batch;
+    if (Fb <= 0) {
+        const double per_frame = (double)n * 64.0 + (host ? (double)frame_stride * sizeof(T) : 0.0);
+        Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 2.0e9 / per_frame));
+        if (Fb >= 8) Fb = (Fb / 8) * 8;
+    }
+    Fb = std::min(Fb, T_frames);
+
+    // device histograms (uint64 == the caller's int64 bit pattern for non-negative counts)
+    unsigned long long* d_qh = nullptr;
+    unsigned long long* d_dh = nullptr;
+    if (host && (qhist || dhist)) {
+        WOL_TRY(c->hist_stage.ensure(sizeof(unsigned long long) * (size_t)(qbins + dbins + 2)));
+        HIP_TRY(hipMemsetAsync(c->hist_stage.p, 0, sizeof(unsigned long long) * (size_t)(qbins + dbins + 2), c->stream));
+        if (qhist) d_qh = c->hist_stage.as<unsigned long long>();
+        if (dhist) d_dh = c->hist_stage.as<unsigned long long>() + qbins;
+    } else {
+        d_qh = reinterpret_cast<unsigned long long*>(qhist);
+        d_dh = reinterpret_cast<unsigned long long*>(dhist);
+    }
+    const bool need_stats = mean || var;
+    const bool q_direct = !host && q_out && std::is_same<T, double>::value;  // q written straight to the caller
+    double* d_stats = nullptr;
+    if (host && need_stats) {
+        WOL_TRY(c->small.ensure(sizeof(double) * 2 * (size_t)T_frames));
+        d_stats = c->small.as<double>();
+    }
+
+    for (int f0 = 0; f0 < T_frames; f0 += Fb) {
+        const int F = std::min(Fb, T_frames - f0);
+        FramesView<T> fv;
+        fv.atom_stride = atom_stride;
+        fv.frame_stride = frame_stride;
+        fv.n = n;
+        if (host) {
+            const size_t elems = (size_t)(F - 1) * frame_stride + (size_t)(n - 1) * atom_stride + 3;
+            WOL_TRY(c->in_stage.ensure(elems * sizeof(T)));
+            HIP_TRY(hipMemcpyAsync(c->in_stage.p, frames + (int64_t)f0 * frame_stride, elems * sizeof(T),
+                                   hipMemcpyHostToDevice, c->stream));
+            fv.base = c->in_stage.as<T>();
+        } else {
+            fv.base = frames + (int64_t)f0 * frame_stride;
+        }
+        QOut out;
+        memset(&out, 0, sizeof out);
+        double* qd = nullptr;
+        if (q_direct) {
+            qd = reinterpret_cast<double*>(q_out) + (int64_t)f0 * n;
+        } else if (need_stats || q_out) {
+            WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)F * n));
+            qd = c->qbuf.as<double>();
+        }
+        out.q = qd;
+        float* q32d = nullptr;
+        if (q_out && !std::is_same<T, double>::value) {
+            if (host) {
+                WOL_TRY(c->out_stage.ensure(sizeof(float) * (size_t)F * n));
+                q32d = c->out_stage.as<float>();
+            } else {
+                q32d = reinterpret_cast<float*>(q_out) + (int64_t)f0 * n;
+            }
+        }
+        out.q32 = q32d;
+        out.qhist = d_qh; out.qbins = qbins;
+        out.dhist = d_dh; out.dbins = dbins; out.dbinwidth = dbinwidth;
+        WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out));
+        if (need_stats) {
+            double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
+            double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
+            hipLaunchKernelGGL(k_frame_stats, dim3(F), dim3(1024), 0, c->stream, qd, n, dm, dv);
+        }
+        if (host && q_out) {
+            if (std::is_same<T, double>::value)
+                HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, qd, sizeof(double) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+            else
+                HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, q32d, sizeof(float) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (host) HIP_TRY(hipStreamSynchronize(c->stream));  // staging buffers are reused by the next batch
+    }
+    if (host) {
+        if (mean) HIP_TRY(hipMemcpyAsync(mean, d_stats, sizeof(double) * (size_t)T_frames, hipMemcpyDeviceToHost, c->stream));
+        if (var) HIP_TRY(hipMemcpyAsync(var, d_stats + T_frames, sizeof(double) * (size_t)T_frames, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (qhist || dhist) {
+            std::vector<unsigned long long> h((size_t)qbins + dbins + 2);
+            HIP_TRY(hipMemcpy(h.data(), c->hist_stage.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+            if (qhist) for (int k = 0; k < qbins; ++k) qhist[k] += (int64_t)h[k];
+            if (dhist) for (int k = 0; k < dbins; ++k) dhist[k] += (int64_t)h[(size_t)qbins + k];
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int wol_version(void) { return 100; }
+
+const char* wol_last_error(void) { return g_err.c_str(); }
+
+int wol_ctx_create(int device, wol_ctx** out) {
+    if (!out) return fail(WOL_ERR_INVALID, "out must not be NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(WOL_ERR_NODEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(WOL_ERR_INVALID, "device %d out of range (have %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    wol_ctx* c = new (std::nothrow) wol_ctx();
+    if (!c) return fail(WOL_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) { delete c; return fail(WOL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
+    c->own_stream = true;
+    *out = c;
+    return WOL_OK;
+}
+
+int wol_ctx_destroy(wol_ctx* c) {
+    if (!c) return WOL_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    DevBuf* bufs[] = {&c->sorted, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
+                      &c->out_stage, &c->hist_stage, &c->small};
+    for (DevBuf* b : bufs) b->release();
+    c->grids_host.release();
+    if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return WOL_OK;
+}
+
+int wol_ctx_set_stream(wol_ctx* c, void* hip_stream) {
+    WOL_TRY(check_ctx(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (hip_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return WOL_OK;
+}
+
+int wol_ctx_synchronize(wol_ctx* c) {
+    WOL_TRY(check_ctx(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return WOL_OK;
+}
+
+int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
+    if (!c || !key) return fail(WOL_ERR_INVALID, "null argument");
+    const std::string k(key);
+    if (k == "cell_width") {
+        if (!(value >= 0.5 && value <= 1e6)) return fail(WOL_ERR_INVALID, "cell_width out of range");
+        c->cell_width = value;
+    } else if (k == "frames_per_batch") {
+        c->frames_per_batch = value < 0 ? 0 : (int)value;
+    } else if (k == "path") {
+        if (value < 0 || value > 3) return fail(WOL_ERR_INVALID, "path must be 0..3");
+        c->path = (int)value;
+    } else if (k == "time_kernels") {
+        c->time_kernels = value != 0.0;
+    } else {
+        return fail(WOL_ERR_INVALID, "unknown option '%s'", key);
+    }
+    return WOL_OK;
+}
+
+int wol_ctx_kernel_time(wol_ctx* c, double* ms_total, int64_t* launches, int reset) {
+    WOL_TRY(check_ctx(c));
+    WOL_TRY(collect_timing(c));
+    if (ms_total) *ms_total = c->ms_total;
+    if (launches) *launches = c->launches;
+    if (reset) { c->ms_total = 0.0; c->launches = 0; }
+    return WOL_OK;
+}
+
+// ---- level 1 ------------------------------------------------------------------------------
+int wol_reimage(wol_ctx* c, const double* pos, int n, const double* refpos, const double* box, double* out) {
+    WOL_TRY(check_ctx(c));
+    if (!pos || !refpos || !box || !out || n < 0) return fail(WOL_ERR_INVALID, "reimage: bad argument");
+    if (n == 0) return WOL_OK;
+    const size_t bytes = sizeof(double) * 3 * (size_t)n;
+    WOL_TRY(c->in_stage.ensure(bytes));
+    WOL_TRY(c->out_stage.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(c->in_stage.p, pos, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_reimage, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->in_stage.as<double>(), n,
+                       refpos[0], refpos[1], refpos[2], make_box(box), c->out_stage.as<double>());
+    HIP_TRY(hipMemcpyAsync(out, c->out_stage.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return WOL_OK;
+}
+
+static int mask_impl(wol_ctx* c, const double* sub, int ns, const double* pos, int n, const double* box,
+                     double low, double high, int32_t* mask) {
+    WOL_TRY(check_ctx(c));
+    if (!pos || !sub || !box || !mask || n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "nearneighbors: bad argument");
+    if (n == 0 || ns == 0) return WOL_OK;
+    const size_t pb = sizeof(double) * 3 * (size_t)n, sb = sizeof(double) * 3 * (size_t)ns;
+    const size_t mb = sizeof(int32_t) * (size_t)n * ns;
+    WOL_TRY(c->in_stage.ensure(pb + sb));
+    WOL_TRY(c->out_stage.ensure(mb));
+    double* dpos = c->in_stage.as<double>();
+    double* dsub = dpos + 3 * (size_t)n;
+    HIP_TRY(hipMemcpyAsync(dpos, pos, pb, hipMemcpyHostToDevice, c->stream));
+    if (sub == pos) dsub = dpos;
+    else HIP_TRY(hipMemcpyAsync(dsub, sub, sb, hipMemcpyHostToDevice, c->stream));
+    PointsView<double> pv{dpos, 3, n}, sv{dsub, 3, ns};
+    const dim3 grid((ns + WOL_BLOCK - 1) / WOL_BLOCK, (n + WOL_MASK_TJ - 1) / WOL_MASK_TJ);
+    hipLaunchKernelGGL(k_brute_mask, grid, dim3(WOL_BLOCK), 0, c->stream, pv, sv, make_box(box), low * low,
+                       high * high, c->out_stage.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(mask, c->out_stage.p, mb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return WOL_OK;
+}
+
+int wol_near_neighbors(wol_ctx* c, const double* sub, int ns, const double* pos, int n, const double* box,
+                       double lowcut, double highcut, int32_t* mask) {
+    return mask_impl(c, sub, ns, pos, n, box, lowcut, highcut, mask);
+}
+
+int wol_all_near_neighbors(wol_ctx* c, const double* pos, int n, const double* box, double lowcut,
+                           double highcut, int32_t* mask) {
+    return mask_impl(c, pos, n, pos, n, box, lowcut, highcut, mask);
+}
+
+int wol_tetra_cos_ang(wol_ctx* c, const double* refpos, const double* neigh, int n, const double* box,
+                      double* allangs) {
+    WOL_TRY(check_ctx(c));
+    if (!refpos || !neigh || !box || !allangs || n < 0) return fail(WOL_ERR_INVALID, "tetracosang: bad argument");
+    if (n == 0) return WOL_OK;
+    const size_t ib = sizeof(double) * 3 * (size_t)n, ob = sizeof(double) * (size_t)n * n;
+    WOL_TRY(c->in_stage.ensure(ib));
+    WOL_TRY(c->out_stage.ensure(ob));
+    HIP_TRY(hipMemcpyAsync(c->in_stage.p, neigh, ib, hipMemcpyHostToDevice, c->stream));
+    const int64_t total = (int64_t)n * n;
+    hipLaunchKernelGGL(k_tetra_cos_ang, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream,
+                       c->in_stage.as<double>(), n, refpos[0], refpos[1], refpos[2], make_box(box),
+                       c->out_stage.as<double>());
+    HIP_TRY(hipMemcpyAsync(allangs, c->out_stage.p, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return WOL_OK;
+}
+
+int wol_lsi_dists(wol_ctx* c, const double* refpos, const double* neigh, int n, const double* box, double* dist) {
+    WOL_TRY(check_ctx(c));
+    if (!refpos || !neigh || !box || !dist || n < 0) return fail(WOL_ERR_INVALID, "lsidists: bad argument");
+    if (n == 0) return WOL_OK;
+    const size_t ib = sizeof(double) * 3 * (size_t)n, ob = sizeof(double) * (size_t)n;
+    WOL_TRY(c->in_stage.ensure(ib));
+    WOL_TRY(c->out_stage.ensure(ob));
+    HIP_TRY(hipMemcpyAsync(c->in_stage.p, neigh, ib, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_lsi_dists, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->in_stage.as<double>(), n,
+                       refpos[0], refpos[1], refpos[2], make_box(box), c->out_stage.as<double>());
+    HIP_TRY(hipMemcpyAsync(dist, c->out_stage.p, ob, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return WOL_OK;
+}
+
+// ---- level 2 ------------------------------------------------------------------------------
+int wol_q_frame(wol_ctx* c, const double* pos, int64_t pos_stride, int n, const double* sub, int64_t sub_stride,
+                int ns, const double* box, double lowcut, double highcut, double* q, int32_t* nn_idx,
+                double* nn_dist, double* ang_deg, int mem) {
+    WOL_TRY(check_ctx(c));
+    if (!pos || !box || !q) return fail(WOL_ERR_INVALID, "q_frame: pos, box and q must not be NULL");
+    if (n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "q_frame: negative size");
+    if (pos_stride < 3 || (sub && sub_stride < 3)) return fail(WOL_ERR_INVALID, "q_frame: stride must be >= 3");
+    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    if (!sub) { ns = n; }
+    if (ns == 0) return WOL_OK;
+    const bool host = (mem == WOL_MEM_HOST);
+    QOut out;
+    memset(&out, 0, sizeof out);
+    FramesView<double> fv;
+    fv.atom_stride = pos_stride;
+    fv.frame_stride = 0;
+    fv.n = n;
+    const double* dsub = sub;
+    if (n == 0) {
+        // no candidates at all: every q is 0 (wp:358), padded outputs
+        std::vector<double> zq((size_t)ns, 0.0);
+        if (host) {
+            memcpy(q, zq.data(), sizeof(double) * (size_t)ns);
+            if (nn_idx) for (size_t k = 0; k < (size_t)ns * 4; ++k) nn_idx[k] = -1;
+            if (nn_dist) for (size_t k = 0; k < (size_t)ns * 4; ++k) nn_dist[k] = NAN;
+            if (ang_deg) for (size_t k = 0; k < (size_t)ns * 6; ++k) ang_deg[k] = NAN;
+            return WOL_OK;
+        }
+        return fail(WOL_ERR_INVALID, "q_frame: n == 0 with device buffers is not supported");
+    }
+    size_t o_q = 0, o_idx = 0, o_dist = 0, o_ang = 0, o_total = 0;
+    if (host) {
+        const size_t pe = (size_t)(n - 1) * pos_stride + 3;
+        const size_t se = sub ? (size_t)(ns - 1) * sub_stride + 3 : 0;
+        WOL_TRY(c->in_stage.ensure(sizeof(double) * (pe + se)));
+        HIP_TRY(hipMemcpyAsync(c->in_stage.p, pos, sizeof(double) * pe, hipMemcpyHostToDevice, c->stream));
+        fv.base = c->in_stage.as<double>();
+        if (sub) {
+            HIP_TRY(hipMemcpyAsync(c->in_stage.as<double>() + pe, sub, sizeof(double) * se, hipMemcpyHostToDevice, c->stream));
+            dsub = c->in_stage.as<double>() + pe;
+        }
+        o_q = 0; o_total = sizeof(double) * (size_t)ns;
+        if (nn_dist) { o_dist = o_total; o_total += sizeof(double) * 4 * (size_t)ns; }
+        if (ang_deg) { o_ang = o_total; o_total += sizeof(double) * 6 * (size_t)ns; }
+        if (nn_idx) { o_idx = o_total; o_total += sizeof(int32_t) * 4 * (size_t)ns; }
+        WOL_TRY(c->out_stage.ensure(o_total));
+        char* ob = c->out_stage.as<char>();
+        out.q = reinterpret_cast<double*>(ob + o_q);
+        out.nn_dist = nn_dist ? reinterpret_cast<double*>(ob + o_dist) : nullptr;
+        out.ang = ang_deg ? reinterpret_cast<double*>(ob + o_ang) : nullptr;
+        out.nn_idx = nn_idx ? reinterpret_cast<int32_t*>(ob + o_idx) : nullptr;
+    } else {
+        fv.base = pos;
+        out.q = q; out.nn_idx = nn_idx; out.nn_dist = nn_dist; out.ang = ang_deg;
+    }
+    WOL_TRY(run_q_batch<double>(c, fv, 1, box, dsub, sub_stride, ns, lowcut, highcut, out));
+    if (host) {
+        char* ob = c->out_stage.as<char>();
+        HIP_TRY(hipMemcpyAsync(q, ob + o_q, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+        if (nn_dist) HIP_TRY(hipMemcpyAsync(nn_dist, ob + o_dist, sizeof(double) * 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+        if (ang_deg) HIP_TRY(hipMemcpyAsync(ang_deg, ob + o_ang, sizeof(double) * 6 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+        if (nn_idx) HIP_TRY(hipMemcpyAsync(nn_idx, ob + o_idx, sizeof(int32_t) * 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return WOL_OK;
+}
+
+int wol_cos_angs(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+                 double lowcut, double highcut, double* ang, double* num_angs, int64_t* total) {
+    (void)c; (void)pos; (void)n; (void)sub; (void)ns; (void)box; (void)lowcut; (void)highcut; (void)ang; (void)num_angs; (void)total;
+    return fail(WOL_ERR_INVALID, "wol_cos_angs: not implemented yet");
+}
+
+int wol_lsi_frame(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+                  double lowcut, double highcut, double* lsi_full, double* num_lsi, int64_t* nvalid) {
+    (void)c; (void)pos; (void)n; (void)sub; (void)ns; (void)box; (void)lowcut; (void)highcut; (void)lsi_full; (void)num_lsi; (void)nvalid;
+    return fail(WOL_ERR_INVALID, "wol_lsi_frame: not implemented yet");
+}
+
+// ---- level 3 ------------------------------------------------------------------------------
+int wol_q_traj(wol_ctx* c, const double* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
+               const double* boxes, double lowcut, double highcut, double* mean, double* var, int64_t* qhist,
+               int qbins, int64_t* dhist, int dbins, double dbinwidth, double* q_out, int mem) {
+    return q_traj_impl<double>(c, frames, atom_stride, frame_stride, T, n, boxes, lowcut, highcut, mean, var,
+                               qhist, qbins, dhist, dbins, dbinwidth, q_out, mem);
+}
+
+int wol_q_traj_f32(wol_ctx* c, const float* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
+                   const double* boxes, double lowcut, double highcut, double* mean, double* var, int64_t* qhist,
+                   int qbins, int64_t* dhist, int dbins, double dbinwidth, float* q_out, int mem) {
+    return q_traj_impl<float>(c, frames, atom_stride, frame_stride, T, n, boxes, lowcut, highcut, mean, var,
+                              qhist, qbins, dhist, dbins, dbinwidth, q_out, mem);
+}
+
+}  // extern "C"

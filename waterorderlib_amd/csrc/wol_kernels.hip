@@ -1,0 +1,463 @@
+// wol_kernels.hip -- gfx950 kernels of libwol.so (included by wol_api.hip).
+//
+// Per batch of frames the q pipeline is
+//   k_bin_count   waters -> cell id + arrival rank (int atomics on the per-frame cell counters)
+//   k_cell_scan   per-frame exclusive scan of the counters -> cell_start[]
+//   k_scatter     counting-sort scatter: sorted[f][start[cell]+rank] = (x, y, z, original index)
+//   k_search_*    per water: walk the cells shell by shell, exact minimum-image arithmetic,
+//                 register top-4, early exit once the 4th key is inside the radius the visited
+//                 shells guarantee; fused epilogue: six angles, q, q/distance histograms in LDS
+//   k_frame_stats per-frame mean / population variance of q (deterministic tree reduction)
+// Nothing N^2-sized is ever stored (the reference materialises an N x N int32 mask,
+// waterlib.f90:836).  k_brute_* are LDS-tiled all-pairs kernels: the f2py-compatible masks, frames
+// with a non-periodic axis, and tiny inputs.
+#include "wol_device.h"
+
+#define WOL_BLOCK 256
+
+// =============================================================================================
+// binning
+// =============================================================================================
+template <typename T>
+struct FramesView {
+    const T* base;
+    int64_t atom_stride;   // in elements of T
+    int64_t frame_stride;  // in elements of T
+    int n;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_bin_count(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ cell_count,
+            int* __restrict__ cellid, int* __restrict__ rank) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (i >= fv.n) return;
+    const FrameGrid& g = grids[f];
+    const T* p = fv.base + (int64_t)f * fv.frame_stride + (int64_t)i * fv.atom_stride;
+    const double x = (double)p[0], y = (double)p[1], z = (double)p[2];
+    const int cx = wol_cell_coord(x, g.box.ib[0], g.nc[0], nullptr);
+    const int cy = wol_cell_coord(y, g.box.ib[1], g.nc[1], nullptr);
+    const int cz = wol_cell_coord(z, g.box.ib[2], g.nc[2], nullptr);
+    const int c = (cz * g.nc[1] + cy) * g.nc[0] + cx;
+    const int r = atomicAdd(&cell_count[g.cell_base + c], 1);
+    cellid[(int64_t)f * fv.n + i] = c;
+    rank[(int64_t)f * fv.n + i] = r;
+}
+
+// exclusive scan of cell_count[0..ncell) in place; cell_count[ncell] receives the total
+__global__ void __launch_bounds__(1024)
+k_cell_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count) {
+    const FrameGrid& g = grids[blockIdx.x];
+    int* c = cell_count + g.cell_base;
+    const int ncell = g.ncell;
+    const int tid = threadIdx.x;
+    const int per = (ncell + 1023) / 1024;
+    const int b = min(tid * per, ncell);
+    const int e = min(b + per, ncell);
+    int s = 0;
+    for (int k = b; k < e; ++k) s += c[k];
+    __shared__ int part[1024];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the partials
+        int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int k = b; k < e; ++k) { int v = c[k]; c[k] = run; run += v; }
+    if (tid == 1023) c[ncell] = part[1023];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start,
+          const int* __restrict__ cellid, const int* __restrict__ rank, double4* __restrict__ sorted) {
+    const int f = blockIdx.y;
+    const int i = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (i >= fv.n) return;
+    const FrameGrid& g = grids[f];
+    const T* p = fv.base + (int64_t)f * fv.frame_stride + (int64_t)i * fv.atom_stride;
+    const int64_t o = (int64_t)f * fv.n;
+    const int dst = cell_start[g.cell_base + cellid[o + i]] + rank[o + i];
+    double4 v;
+    v.x = (double)p[0]; v.y = (double)p[1]; v.z = (double)p[2];
+    v.w = __longlong_as_double((long long)i);
+    sorted[o + dst] = v;
+}
+
+// =============================================================================================
+// epilogue shared by the search kernels
+// =============================================================================================
+struct QOut {
+    double* q;          // [F][ns] or null
+    float* q32;         // [F][ns] or null (float32 storage variant)
+    int32_t* nn_idx;    // [F][ns][4] or null
+    double* nn_dist;    // [F][ns][4] or null
+    double* ang;        // [F][ns][6] or null
+    unsigned long long* qhist;  // [qbins] or null
+    unsigned long long* dhist;  // [dbins] or null
+    int qbins, dbins;
+    double dbinwidth;
+};
+
+// P* are the coordinates of the selected neighbours as stored (not yet re-imaged)
+__device__ __forceinline__ void wol_finish_water(const double a[3], const Top4& t, const double N0[3],
+                                                 const double N1[3], const double N2[3], const double N3[3],
+                                                 const Box3& b, const QOut& o, int64_t slot,
+                                                 int* __restrict__ lds_qh, int* __restrict__ lds_dh) {
+    double P0[3] = {0, 0, 0}, P1[3] = {0, 0, 0}, P2[3] = {0, 0, 0}, P3[3] = {0, 0, 0};
+    const int nb = t.n;
+    if (nb >= 1) wol_neighbour_point(a, N0[0], N0[1], N0[2], b, P0);
+    if (nb >= 2) wol_neighbour_point(a, N1[0], N1[1], N1[2], b, P1);
+    if (nb >= 3) wol_neighbour_point(a, N2[0], N2[1], N2[2], b, P2);
+    if (nb >= 4) wol_neighbour_point(a, N3[0], N3[1], N3[2], b, P3);
+    double ang[6];
+    const double q = wol_q_from_points(a, P0, P1, P2, P3, nb, ang);
+    if (o.q) o.q[slot] = q;
+    if (o.q32) o.q32[slot] = (float)q;
+    const double nanv = __builtin_nan("");
+    if (o.nn_idx) {
+        int4 v;
+        v.x = nb >= 1 ? t.j0 : -1; v.y = nb >= 2 ? t.j1 : -1; v.z = nb >= 3 ? t.j2 : -1; v.w = nb >= 4 ? t.j3 : -1;
+        reinterpret_cast<int4*>(o.nn_idx)[slot] = v;
+    }
+    if (o.nn_dist) {
+        double* d = o.nn_dist + slot * 4;
+        d[0] = nb >= 1 ? t.d0 : nanv; d[1] = nb >= 2 ? t.d1 : nanv;
+        d[2] = nb >= 3 ? t.d2 : nanv; d[3] = nb >= 4 ? t.d3 : nanv;
+    }
+    if (o.ang) {
+        double* d = o.ang + slot * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = ang[k];
+    }
+    if (lds_qh) {
+        const int bin = wol_np_hist_bin(q, o.qbins, 0.0, 1.0);
+        if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
+    }
+    if (lds_dh) {
+        int bin;
+        if (nb >= 1 && (bin = wol_dist_bin(t.d0, o.dbinwidth, o.dbins)) >= 0) atomicAdd(&lds_dh[bin], 1);
+        if (nb >= 2 && (bin = wol_dist_bin(t.d1, o.dbinwidth, o.dbins)) >= 0) atomicAdd(&lds_dh[bin], 1);
+        if (nb >= 3 && (bin = wol_dist_bin(t.d2, o.dbinwidth, o.dbins)) >= 0) atomicAdd(&lds_dh[bin], 1);
+        if (nb >= 4 && (bin = wol_dist_bin(t.d3, o.dbinwidth, o.dbins)) >= 0) atomicAdd(&lds_dh[bin], 1);
+    }
+}
+
+__device__ __forceinline__ void wol_hist_zero(int* lds, int nbins) {
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) lds[k] = 0;
+}
+__device__ __forceinline__ void wol_hist_flush(const int* lds, int nbins, unsigned long long* g) {
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+        const int v = lds[k];
+        if (v) atomicAdd(&g[k], (unsigned long long)v);
+    }
+}
+
+// =============================================================================================
+// exact cell-list search
+// =============================================================================================
+struct SearchArgs {
+    const FrameGrid* grids;
+    const double4* sorted;   // [F][n]
+    const int* cell_start;
+    int n, F;
+    const double* sub;       // external queries (single frame) or null = the waters themselves
+    int64_t sub_stride;
+    int ns;                  // queries per frame
+    double lowsq, highsq, high;
+    QOut out;
+    int tiles_per_frame;
+    int xcd_affine;
+};
+
+// tile -> (frame, tile in frame).  With >= 8 frames in flight the 8 XCDs (blocks b and b+8 share
+// one, dealt round-robin) each walk their own frames so a frame's sorted array stays in that
+// XCD's 4 MiB L2; speed only, never correctness.
+__device__ __forceinline__ bool wol_tile_of(const SearchArgs& a, int it, int* frame, int* tile) {
+    if (a.xcd_affine) {
+        const int xcd = blockIdx.x & 7;
+        const int k = blockIdx.x >> 3;
+        const int K = gridDim.x >> 3;
+        const int64_t m = (int64_t)it * K + k;
+        const int fi = (int)(m / a.tiles_per_frame);
+        const int f = fi * 8 + xcd;
+        if (f >= a.F) return false;
+        *frame = f;
+        *tile = (int)(m % a.tiles_per_frame);
+        return true;
+    }
+    const int64_t m = (int64_t)it * gridDim.x + blockIdx.x;
+    if (m >= (int64_t)a.F * a.tiles_per_frame) return false;
+    *frame = (int)(m / a.tiles_per_frame);
+    *tile = (int)(m % a.tiles_per_frame);
+    return true;
+}
+
+__device__ __forceinline__ int wol_wrap_cell(int c, int nc) {
+    c += (c < 0) ? nc : 0;
+    c -= (c >= nc) ? nc : 0;
+    return c;
+}
+
+// exact search of one query point c against frame grid g; returns the top-4 (slots into sp)
+__device__ __forceinline__ void wol_search_exact_one(const double c[3], const FrameGrid& g,
+                                                     const double4* __restrict__ sp,
+                                                     const int* __restrict__ cs, double lowsq,
+                                                     double highsq, double high, Top4& t) {
+    double fr[3];
+    int cc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cc[k] = wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr[k]);
+    top4_init(t);
+    for (int shell = 0; shell <= g.maxshell; ++shell) {
+        const int zl = max(-shell, -g.lo[2]), zh = min(shell, g.hi[2]);
+        const int yl = max(-shell, -g.lo[1]), yh = min(shell, g.hi[1]);
+        const int xl = max(-shell, -g.lo[0]), xh = min(shell, g.hi[0]);
+        for (int dz = zl; dz <= zh; ++dz) {
+            const int cz = wol_wrap_cell(cc[2] + dz, g.nc[2]);
+            for (int dy = yl; dy <= yh; ++dy) {
+                const int cy = wol_wrap_cell(cc[1] + dy, g.nc[1]);
+                const bool face = (abs(dz) == shell) || (abs(dy) == shell);
+                for (int dx = xl; dx <= xh; ++dx) {
+                    if (!face && abs(dx) != shell) continue;  // interior of the cube: done in earlier shells
+                    const int cx = wol_wrap_cell(cc[0] + dx, g.nc[0]);
+                    const int cell = (cz * g.nc[1] + cy) * g.nc[0] + cx;
+                    const int b = cs[cell], e = cs[cell + 1];
+                    for (int j = b; j < e; ++j) {
+                        const double4 v = sp[j];
+                        double dist;
+                        bool in_mask;
+                        if (wol_eval_pair(c, v.x, v.y, v.z, g.box, lowsq, highsq, t.bound2, &dist, &in_mask))
+                            top4_insert(t, dist, (int)__double_as_longlong(v.w), j);
+                    }
+                }
+            }
+        }
+        // radius guaranteed complete after this shell: along each axis the visited slab reaches
+        // shell*cw + (distance to the nearer wall of the own cell); an axis whose cells have all
+        // been visited imposes no limit
+        double rg = __builtin_huge_val();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool all = (shell >= g.lo[k]) && (shell >= g.hi[k]) && (g.lo[k] + g.hi[k] + 1 >= g.nc[k]);
+            if (!all) {
+                const double wall = fmin(fr[k], 1.0 - fr[k]) * g.cw[k];
+                rg = fmin(rg, (double)shell * g.cw[k] + wall);
+            }
+        }
+        rg -= 1e-6;  // binning rounds at cell walls; a micro-angstrom of slack covers it
+        if (rg >= high) break;
+        if (t.n == 4 && t.d3 <= rg) break;
+    }
+}
+
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_search_exact(SearchArgs a) {
+    extern __shared__ int lds_hist[];
+    int* lds_qh = a.out.qhist ? lds_hist : nullptr;
+    int* lds_dh = a.out.dhist ? lds_hist + (a.out.qhist ? a.out.qbins : 0) : nullptr;
+    if (lds_qh) wol_hist_zero(lds_qh, a.out.qbins);
+    if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
+    __syncthreads();
+
+    for (int it = 0;; ++it) {
+        int f, tile;
+        if (!wol_tile_of(a, it, &f, &tile)) break;
+        const int s = tile * WOL_BLOCK + threadIdx.x;
+        if (s >= a.ns) continue;
+        const FrameGrid& g = a.grids[f];
+        if (g.maxshell < 0) continue;  // frame handled by the all-pairs kernel
+        const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+        const int* __restrict__ cs = a.cell_start + g.cell_base;
+        double c[3];
+        int out_row;
+        if (a.sub) {
+            const double* p = a.sub + (int64_t)s * a.sub_stride;
+            c[0] = p[0]; c[1] = p[1]; c[2] = p[2];
+            out_row = s;
+        } else {
+            const double4 v = sp[s];
+            c[0] = v.x; c[1] = v.y; c[2] = v.z;
+            out_row = (int)__double_as_longlong(v.w);
+        }
+        Top4 t;
+        wol_search_exact_one(c, g, sp, cs, a.lowsq, a.highsq, a.high, t);
+        const double4 n0 = sp[t.s0], n1 = sp[t.s1], n2 = sp[t.s2], n3 = sp[t.s3];
+        const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
+        const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
+        wol_finish_water(c, t, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + out_row, lds_qh, lds_dh);
+    }
+    __syncthreads();
+    if (lds_qh) wol_hist_flush(lds_qh, a.out.qbins, a.out.qhist);
+    if (lds_dh) wol_hist_flush(lds_dh, a.out.dbins, a.out.dhist);
+}
+
+// =============================================================================================
+// LDS-tiled all-pairs kernels (exact arithmetic, any box incl. non-periodic axes)
+// =============================================================================================
+template <typename T>
+struct PointsView {
+    const T* base;
+    int64_t stride;  // elements of T between rows
+    int n;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_brute_q(PointsView<T> pos, PointsView<T> sub, Box3 box, double lowsq, double highsq, QOut out,
+          int64_t out_base) {
+    extern __shared__ int lds_hist[];
+    __shared__ double tx[WOL_BLOCK], ty[WOL_BLOCK], tz[WOL_BLOCK];
+    int* lds_qh = out.qhist ? lds_hist : nullptr;
+    int* lds_dh = out.dhist ? lds_hist + (out.qhist ? out.qbins : 0) : nullptr;
+    if (lds_qh) wol_hist_zero(lds_qh, out.qbins);
+    if (lds_dh) wol_hist_zero(lds_dh, out.dbins);
+
+    const int s = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    const bool active = s < sub.n;
+    double c[3] = {0.0, 0.0, 0.0};
+    if (active) {
+        const T* p = sub.base + (int64_t)s * sub.stride;
+        c[0] = (double)p[0]; c[1] = (double)p[1]; c[2] = (double)p[2];
+    }
+    Top4 t;
+    top4_init(t);
+    for (int j0 = 0; j0 < pos.n; j0 += WOL_BLOCK) {
+        __syncthreads();
+        const int j = j0 + threadIdx.x;
+        if (j < pos.n) {
+            const T* p = pos.base + (int64_t)j * pos.stride;
+            tx[threadIdx.x] = (double)p[0]; ty[threadIdx.x] = (double)p[1]; tz[threadIdx.x] = (double)p[2];
+        }
+        __syncthreads();
+        const int cnt = min(WOL_BLOCK, pos.n - j0);
+        if (active) {
+            for (int k = 0; k < cnt; ++k) {
+                double dist;
+                bool in_mask;
+                if (wol_eval_pair(c, tx[k], ty[k], tz[k], box, lowsq, highsq, t.bound2, &dist, &in_mask))
+                    top4_insert(t, dist, j0 + k, j0 + k);
+            }
+        }
+    }
+    if (active) {
+        double N[4][3];
+        const int sl[4] = {t.s0, t.s1, t.s2, t.s3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const T* p = pos.base + (int64_t)(k < t.n ? sl[k] : 0) * pos.stride;
+            N[k][0] = (double)p[0]; N[k][1] = (double)p[1]; N[k][2] = (double)p[2];
+        }
+        wol_finish_water(c, t, N[0], N[1], N[2], N[3], box, out, out_base + s, lds_qh, lds_dh);
+    }
+    __syncthreads();
+    if (lds_qh) wol_hist_flush(lds_qh, out.qbins, out.qhist);
+    if (lds_dh) wol_hist_flush(lds_dh, out.dbins, out.dhist);
+}
+
+// f2py-compatible mask: int32, Fortran order (ns, n): element (i,j) at i + j*ns.
+// waterlib.f90:710-743 / 830-862 (the all-pairs form is the same predicate, exactly symmetric).
+#define WOL_MASK_TJ 64
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_brute_mask(PointsView<double> pos, PointsView<double> sub, Box3 box, double lowsq, double highsq,
+             int32_t* __restrict__ mask) {
+    __shared__ double tx[WOL_MASK_TJ], ty[WOL_MASK_TJ], tz[WOL_MASK_TJ];
+    const int i = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    const int j0 = blockIdx.y * WOL_MASK_TJ;
+    if (threadIdx.x < WOL_MASK_TJ && j0 + threadIdx.x < pos.n) {
+        const double* p = pos.base + (int64_t)(j0 + threadIdx.x) * pos.stride;
+        tx[threadIdx.x] = p[0]; ty[threadIdx.x] = p[1]; tz[threadIdx.x] = p[2];
+    }
+    __syncthreads();
+    if (i >= sub.n) return;
+    const double* q = sub.base + (int64_t)i * sub.stride;
+    const double a0 = q[0], a1 = q[1], a2 = q[2];
+    const int cnt = min(WOL_MASK_TJ, pos.n - j0);
+    for (int k = 0; k < cnt; ++k) {
+        const double dx = wol_minimg1(tx[k] - a0, box.L[0], box.ib[0]);
+        const double dy = wol_minimg1(ty[k] - a1, box.L[1], box.ib[1]);
+        const double dz = wol_minimg1(tz[k] - a2, box.L[2], box.ib[2]);
+        const double d2 = wol_sumsq(dx, dy, dz);
+        mask[(int64_t)i + (int64_t)(j0 + k) * sub.n] = (d2 > lowsq && d2 <= highsq) ? 1 : 0;
+    }
+}
+
+// =============================================================================================
+// per-frame statistics of q: np.mean and np.var (ddof=0) -- orderParam_lib.py:1473.
+// Fixed-order tree reduction => run-to-run bit-reproducible (numpy's pairwise order differs in
+// the last ulps; tests compare at 1e-12).
+// =============================================================================================
+__device__ __forceinline__ double wol_block_sum(double v, double* sm) {
+    const int tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if (tid < off) sm[tid] += sm[tid + off];
+        __syncthreads();
+    }
+    const double r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(1024)
+k_frame_stats(const double* __restrict__ q, int n, double* __restrict__ mean, double* __restrict__ var) {
+    __shared__ double sm[1024];
+    const double* qf = q + (int64_t)blockIdx.x * n;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += qf[i];
+    const double m = wol_block_sum(s, sm) / (double)n;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double d = qf[i] - m; v += d * d; }
+    const double vv = wol_block_sum(v, sm) / (double)n;
+    if (threadIdx.x == 0) {
+        if (mean) mean[blockIdx.x] = m;
+        if (var) var[blockIdx.x] = vv;
+    }
+}
+
+// =============================================================================================
+// level-1 waterlib routines (tiny; kept on the GPU so the product has no CPU compute path)
+// =============================================================================================
+__global__ void k_reimage(const double* __restrict__ pos, int n, double r0, double r1, double r2, Box3 box,
+                          double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ref[3] = {r0, r1, r2};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double d = wol_minimg1(pos[3 * (int64_t)i + k] - ref[k], box.L[k], box.ib[k]);
+        out[3 * (int64_t)i + k] = ref[k] + d;  // waterlib.f90:45
+    }
+}
+
+__global__ void k_tetra_cos_ang(const double* __restrict__ neigh, int n, double r0, double r1, double r2,
+                                Box3 box, double* __restrict__ allangs) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t)n * n) return;
+    const int i = (int)(id / n), j = (int)(id % n);
+    if (i == j) { allangs[id] = 0.0; return; }
+    const int u = min(i, j), v = max(i, j);
+    const double ref[3] = {r0, r1, r2};
+    double p1[3], p2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        p1[k] = ref[k] + wol_minimg1(neigh[3 * (int64_t)u + k] - ref[k], box.L[k], box.ib[k]);
+        p2[k] = ref[k] + wol_minimg1(neigh[3 * (int64_t)v + k] - ref[k], box.L[k], box.ib[k]);
+    }
+    allangs[id] = wol_cos_angle3(p1, ref, p2);
+}
+
+__global__ void k_lsi_dists(const double* __restrict__ neigh, int n, double r0, double r1, double r2, Box3 box,
+                            double* __restrict__ dist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dx = wol_minimg1(neigh[3 * (int64_t)i] - r0, box.L[0], box.ib[0]);
+    const double dy = wol_minimg1(neigh[3 * (int64_t)i + 1] - r1, box.L[1], box.ib[1]);
+    const double dz = wol_minimg1(neigh[3 * (int64_t)i + 2] - r2, box.L[2], box.ib[2]);
+    dist[i] = sqrt(wol_sumsq(dx, dy, dz));
+}

@@ -1,0 +1,107 @@
+"""Drop-in for the hot-path functions of the reference's structureLibs/water_properties.py:
+``getOrderParamq`` (:344-391), ``getCosAngs`` (:210-250), ``getLSI`` (:252-311) and
+``tetrahedralMetrics`` (:314-342) -- same names, arguments, defaults and return values.  Instead of
+an N x N mask plus a per-water Python loop around f2py calls, each call is ONE trip through the C
+ABI into fused HIP kernels (include/wol.h: wol_q_frame / wol_cos_angs / wol_lsi_frame).
+
+    import waterorderlib_amd.water_properties as wp
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+watdens = 0.033456  # molecules or oxygens per Angstrom ^ 3 near 300 K (water_properties.py:55)
+
+
+def _pos(a, name):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("%s must have shape (n,3), got %s" % (name, a.shape))
+    return np.ascontiguousarray(a)
+
+
+def _same(subPos, Pos):
+    # the reference picks the allnearneighbors branch with np.array_equal(subPos, Pos) (wp:363)
+    return subPos is Pos or (subPos.shape == Pos.shape and np.array_equal(subPos, Pos))
+
+
+def getOrderParamq(subPos, Pos, BoxDims, lowCut=0.0, highCut=10.0, full=False, ctx=None):
+    """Tetrahedral order parameter q of Errington & Debenedetti for every row of subPos
+    (water_properties.py:344-391).  ``full=True`` additionally returns
+    (nn_idx[ns,4] int32, nn_dist[ns,4], ang_deg[ns,6]): the four nearest neighbours (indices into
+    Pos, -1 padded), their distances (NaN padded) and the six angles that entered q."""
+    Pos = _pos(Pos, "Pos")
+    subPos = Pos if subPos is Pos else _pos(subPos, "subPos")
+    box = _lib.box3(BoxDims)
+    ctx = ctx or _lib.default_context()
+    ns = len(subPos)
+    q = np.zeros(ns, dtype=np.float64)
+    idx = np.full((ns, 4), -1, dtype=np.int32) if full else None
+    dist = np.full((ns, 4), np.nan) if full else None
+    ang = np.full((ns, 6), np.nan) if full else None
+    if ns:
+        sub = None if _same(subPos, Pos) else subPos
+        _lib.check(_lib.load().wol_q_frame(ctx.handle, _lib.ptr(Pos), 3, len(Pos), _lib.ptr(sub), 3, ns,
+                                           _lib.ptr(box), float(lowCut), float(highCut), _lib.ptr(q),
+                                           _lib.ptr(idx), _lib.ptr(dist), _lib.ptr(ang), _lib.MEM_HOST))
+    return (q, idx, dist, ang) if full else q
+
+
+def getCosAngs(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.413, ctx=None):
+    """All three-body angles (degrees) between the neighbours in the shell lowCut < d <= highCut of
+    every row of subPos, flattened in water order, and the number of shell neighbours per water
+    (water_properties.py:210-250).  Returns (angVals, numAngs)."""
+    Pos = _pos(Pos, "Pos")
+    subPos = Pos if subPos is Pos else _pos(subPos, "subPos")
+    box = _lib.box3(BoxDims)
+    ctx = ctx or _lib.default_context()
+    ns = len(subPos)
+    num = np.zeros(ns, dtype=np.float64)
+    if ns == 0 or len(Pos) == 0:
+        return np.array([]), num
+    sub = None if _same(subPos, Pos) else subPos
+    total = C.c_int64(0)
+    L = _lib.load()
+    args = (ctx.handle, _lib.ptr(Pos), len(Pos), _lib.ptr(sub), ns, _lib.ptr(box), float(lowCut), float(highCut))
+    _lib.check(L.wol_cos_angs(*args, None, _lib.ptr(num), C.byref(total)))
+    ang = np.empty(total.value, dtype=np.float64)
+    if total.value:
+        _lib.check(L.wol_cos_angs(*args, _lib.ptr(ang), _lib.ptr(num), C.byref(total)))
+    return ang, num
+
+
+def getLSI(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7, ctx=None):
+    """Local structure index of Shiratani & Sasai per water (water_properties.py:252-311).
+    Returns (lsiVals, numLSI); waters the reference skips are absent from lsiVals."""
+    Pos = _pos(Pos, "Pos")
+    subPos = Pos if subPos is Pos else _pos(subPos, "subPos")
+    box = _lib.box3(BoxDims)
+    ctx = ctx or _lib.default_context()
+    ns = len(subPos)
+    num = np.zeros(ns, dtype=np.float64)
+    if ns == 0 or len(Pos) == 0:
+        return np.array([]), num
+    sub = None if _same(subPos, Pos) else subPos
+    full = np.empty(ns, dtype=np.float64)
+    nvalid = C.c_int64(0)
+    _lib.check(_lib.load().wol_lsi_frame(ctx.handle, _lib.ptr(Pos), len(Pos), _lib.ptr(sub), ns, _lib.ptr(box),
+                                         float(lowCut), float(highCut), _lib.ptr(full), _lib.ptr(num),
+                                         C.byref(nvalid)))
+    return full[~np.isnan(full)], num
+
+
+def tetrahedralMetrics(angVals, nBins=500, binRange=[0.0, 180.0]):
+    """water_properties.py:314-342 -- host-side numpy post-processing of the angle list (kept
+    verbatim in behaviour: histogram, tetrahedral fraction in [100,120] deg, <cos>, var cos, entropy)."""
+    angVals = np.asarray(angVals, dtype=np.float64)
+    angDist, bins = np.histogram(angVals, bins=nBins, range=binRange, density=False)
+    angTet = angVals[np.where((angVals >= 100.0) & (angVals <= 120.0))[0]]
+    fracTet = float(len(angTet)) / float(len(angVals))
+    avgCos = np.mean(np.cos(angTet * np.pi / 180.0))
+    varCos = np.var(np.cos(angTet * np.pi / 180.0))
+    angDens = angDist / float(np.sum(angDist))
+    angDens = angDens[np.where(angDens != 0)[0]]
+    entropy = -np.sum(angDens * np.log(angDens))
+    return angDist, bins, fracTet, avgCos, varCos, entropy

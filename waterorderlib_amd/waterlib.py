@@ -1,0 +1,87 @@
+"""Drop-in for the reference's f2py module ``waterlib`` (built from fortran/waterlib.f90 by
+fortran/buildWrappers.sh:3-5), restricted to the routines on the q / 4-NN / angle path.
+
+Same names (lower-cased by f2py), argument order, optional trailing dimension arguments, dtypes
+and memory order as the f2py wrappers: ``logical`` results come back as Fortran-ordered int32,
+rank-2 real results as Fortran-ordered float64.  The work is done by libwol.so on the GPU; there is
+no CPU path.
+
+    import waterorderlib_amd.waterlib as wl      # instead of: import waterlib as wl
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _pos(a, name):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("%s must have shape (n,3), got %s" % (name, a.shape))
+    return np.ascontiguousarray(a)
+
+
+def _vec3(a, name):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if a.size != 3:
+        raise ValueError("%s must have 3 elements" % name)
+    return a
+
+
+def reimage(pos, refpos, boxl, npos=None, dim=None):
+    """reimagedpos = reimage(pos,refpos,boxl,[npos,dim])   -- waterlib.f90:32-47"""
+    pos = _pos(pos, "pos")
+    if (npos is not None and npos != len(pos)) or (dim is not None and dim != 3):
+        raise ValueError("npos/dim do not match pos")
+    ref = _vec3(refpos, "refpos"); box = _lib.box3(boxl)
+    out = np.empty_like(pos)
+    _lib.check(_lib.load().wol_reimage(_lib.default_context().handle, _lib.ptr(pos), len(pos), _lib.ptr(ref),
+                                       _lib.ptr(box), _lib.ptr(out)))
+    return np.asfortranarray(out)
+
+
+def nearneighbors(subpos, pos, boxl, lowcut, highcut, nsubpos=None, npos=None):
+    """nneighbors = nearneighbors(subpos,pos,boxl,lowcut,highcut,[nsubpos,npos]) -- waterlib.f90:710-743"""
+    sub = _pos(subpos, "subpos"); pos = _pos(pos, "pos"); box = _lib.box3(boxl)
+    if (nsubpos is not None and nsubpos != len(sub)) or (npos is not None and npos != len(pos)):
+        raise ValueError("nsubpos/npos do not match the arrays")
+    mask = np.zeros((len(sub), len(pos)), dtype=np.int32, order="F")
+    _lib.check(_lib.load().wol_near_neighbors(_lib.default_context().handle, _lib.ptr(sub), len(sub), _lib.ptr(pos),
+                                              len(pos), _lib.ptr(box), float(lowcut), float(highcut), _lib.ptr(mask)))
+    return mask
+
+
+def allnearneighbors(pos, boxl, lowcut, highcut, npos=None):
+    """nneighbors = allnearneighbors(pos,boxl,lowcut,highcut,[npos]) -- waterlib.f90:830-862"""
+    pos = _pos(pos, "pos"); box = _lib.box3(boxl)
+    if npos is not None and npos != len(pos):
+        raise ValueError("npos does not match pos")
+    mask = np.zeros((len(pos), len(pos)), dtype=np.int32, order="F")
+    _lib.check(_lib.load().wol_all_near_neighbors(_lib.default_context().handle, _lib.ptr(pos), len(pos),
+                                                  _lib.ptr(box), float(lowcut), float(highcut), _lib.ptr(mask)))
+    return mask
+
+
+def tetracosang(refpos, neighpos, boxl, nneighpos=None):
+    """allangs = tetracosang(refpos,neighpos,boxl,[nneighpos]) -- waterlib.f90:867-895 (degrees;
+    the diagonal, which the reference leaves uninitialised, is 0)"""
+    ref = _vec3(refpos, "refpos"); nb = _pos(neighpos, "neighpos"); box = _lib.box3(boxl)
+    if nneighpos is not None and nneighpos != len(nb):
+        raise ValueError("nneighpos does not match neighpos")
+    n = len(nb)
+    out = np.zeros((n, n), dtype=np.float64)
+    _lib.check(_lib.load().wol_tetra_cos_ang(_lib.default_context().handle, _lib.ptr(ref), _lib.ptr(nb), n,
+                                             _lib.ptr(box), _lib.ptr(out)))
+    return np.asfortranarray(out)
+
+
+def lsidists(refpos, neighpos, boxl, nneighpos=None):
+    """dist1 = lsidists(refpos,neighpos,boxl,[nneighpos]) -- waterlib.f90:900-918"""
+    ref = _vec3(refpos, "refpos"); nb = _pos(neighpos, "neighpos"); box = _lib.box3(boxl)
+    if nneighpos is not None and nneighpos != len(nb):
+        raise ValueError("nneighpos does not match neighpos")
+    out = np.empty(len(nb), dtype=np.float64)
+    _lib.check(_lib.load().wol_lsi_dists(_lib.default_context().handle, _lib.ptr(ref), _lib.ptr(nb), len(nb),
+                                         _lib.ptr(box), _lib.ptr(out)))
+    return out
