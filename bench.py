@@ -50,6 +50,7 @@ def cpu_baseline(pos_host, box, sample_waters, threads):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wol_oracle
     wol_oracle.lib()
+    threads = wol_oracle.set_threads(min(threads, 16))  # the GPU box's CPU share for one GPU
     n = len(pos_host)
     sub = np.ascontiguousarray(pos_host[:sample_waters])
     t0 = time.perf_counter()
@@ -148,6 +149,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     k_ms, k_launches = ctx.kernel_time(reset=False)
+    slow_last = ctx.counter("slow_waters")
 
     if rank == 0:
         frames_total = world * args.steps * F
@@ -173,6 +175,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": args.traffic_bytes,
                          "launches": int(k_launches), "avg_launch_ms": k_avg_s * 1e3,
+                         "exact_path_fraction_last_launch": slow_last / float(F * n),
                          "alg_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

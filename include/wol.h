@@ -59,6 +59,10 @@ int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
 int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int reset);
 
+/* diagnostic counters of the LAST q call on this context (synchronises the stream):
+ * "slow_waters" = waters the fp32 filter could not certify and the exact search finished */
+int wol_ctx_get_counter(wol_ctx* ctx, const char* key, int64_t* value);
+
 /* ---- level 1: the f2py `waterlib` routines on the path (host pointers) -------------------- */
 /* waterlib.f90:32-47 reimage(Pos,RefPos,BoxL) -> ReimagedPos(NPos,3); pos/out row-major [n][3] */
 int wol_reimage(wol_ctx* ctx, const double* pos, int n, const double* refpos, const double* box,

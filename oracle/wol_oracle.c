@@ -38,7 +38,22 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
 #define WOLO_PI 3.1415926535897931
+
+/* thread count of the OpenMP cell-list form (bench.py's cpu_baseline states it) */
+int wolo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 static inline void ibox_of(const double box[3], double ib[3]) {
     for (int k = 0; k < 3; ++k) ib[k] = (box[k] >= 0.0) ? 1.0 / box[k] : 0.0;

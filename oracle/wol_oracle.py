@@ -45,6 +45,11 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """OpenMP threads used by the cell-list form; returns the effective count."""
+    return lib().wolo_set_threads(C.c_int(int(n)))
+
+
 def _d(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

@@ -22,10 +22,10 @@ def wp():
 
 @pytest.fixture(scope="module")
 def ctxs():
-    """one context per search path: 0 auto, 1 all-pairs, 2 exact cell list"""
+    """one context per search path: 0 auto, 1 all-pairs, 2 exact cell list, 3 fp32-filtered cell list"""
     from waterorderlib_amd import _lib
     out = {}
-    for path in (0, 1, 2):
+    for path in (0, 1, 2, 3):
         c = _lib.Context(0)
         c.set_option("path", path)
         out[path] = c
@@ -42,7 +42,7 @@ def check_full(res, g_q, g_idx, g_dist, g_ang):
     np.testing.assert_allclose(q, g_q, rtol=0, atol=Q_TOL)
 
 
-@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("path", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", Q_CASES)
 def test_q_golden(wp, ctxs, name, path):
     g = golden(name)
@@ -51,11 +51,13 @@ def test_q_golden(wp, ctxs, name, path):
     check_full(res, g["q"], g["nn_idx"], g["nn_dist"], g["ang"])
     # plain call returns q only, like the reference
     q = wp.getOrderParamq(sub, pos, box, lo, hi, ctx=ctxs[path])
-    assert q.shape == (len(sub),) and np.array_equal(q, res[0])
+    assert q.shape == (len(sub),)
+    np.testing.assert_allclose(q, res[0], rtol=0, atol=1e-13)  # q-only calls may skip the acos/cos round trip
 
 
-@pytest.mark.parametrize("path", [1, 2])
-@pytest.mark.parametrize("n,seed,cw", [(3000, 21, 5.0), (3000, 22, 3.1), (10000, 23, 5.0), (4097, 24, 7.7)])
+@pytest.mark.parametrize("path", [1, 2, 3])
+@pytest.mark.parametrize("n,seed,cw", [(3000, 21, 5.0), (3000, 22, 3.1), (10000, 23, 5.0), (4097, 24, 7.7),
+                                       (20000, 25, 4.2), (1500, 26, 5.0)])
 def test_q_vs_oracle(wp, ctxs, oracle, n, seed, cw, path):
     from waterorderlib_amd import synth
     xyz, boxes = synth.water_frames(n, 1, seed=seed)
@@ -74,6 +76,10 @@ def test_q_gas_and_subsets_vs_oracle(wp, ctxs, oracle):
     pos = pos * np.array([1.0, 1.3, 0.8])
     ref = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
     check_full(wp.getOrderParamq(pos, pos, box, full=True, ctx=ctxs[2]), *ref)
+    check_full(wp.getOrderParamq(pos, pos, box, full=True, ctx=ctxs[3]), *ref)
+    assert 0 < ctxs[3].counter("slow_waters") < len(pos)  # the gas has sparse spots the filter must hand over
+    # q-only call (no angle outputs): q comes straight from the cosines, within 2e-14 of the round trip
+    np.testing.assert_allclose(wp.getOrderParamq(pos, pos, box, ctx=ctxs[3]), ref[0], rtol=0, atol=1e-13)
     # sub-population branch through the cell path: rows of pos and arbitrary points
     rng = np.random.default_rng(5)
     rows = pos[rng.choice(len(pos), 700, replace=False)]
@@ -95,7 +101,7 @@ def test_slab_with_vapour(wp, ctxs, oracle):
     pos, box = xyz[0], boxes[0]
     ref = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
     assert (ref[1][:, 3] < 0).sum() > 0
-    for path in (1, 2):
+    for path in (1, 2, 3):
         check_full(wp.getOrderParamq(pos, pos, box, full=True, ctx=ctxs[path]), *ref)
 
 

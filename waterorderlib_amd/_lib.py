@@ -17,7 +17,7 @@ _lp = C.POINTER(C.c_int64)
 _vp = C.c_void_p
 
 SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy", "wol_ctx_set_stream",
-           "wol_ctx_synchronize", "wol_ctx_set_option", "wol_ctx_kernel_time", "wol_reimage",
+           "wol_ctx_synchronize", "wol_ctx_set_option", "wol_ctx_kernel_time", "wol_ctx_get_counter", "wol_reimage",
            "wol_near_neighbors", "wol_all_near_neighbors", "wol_tetra_cos_ang", "wol_lsi_dists",
            "wol_q_frame", "wol_cos_angs", "wol_lsi_frame", "wol_q_traj", "wol_q_traj_f32"]
 
@@ -28,6 +28,25 @@ class WolError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 (same soname,
+    libamdhip64.so.7, as /opt/rocm's).  libwol.so must bind to the copy torch uses, otherwise two
+    runtimes initialise the GPU and the second finds none; device pointers and streams handed over
+    from torch also only make sense inside torch's runtime.  So: if torch is installed, map its
+    libamdhip64 first (without importing torch); libwol's NEEDED entry then resolves to it by
+    soname.  Without torch, libwol's RUNPATH (/opt/rocm/lib) applies."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads libwol.so; raises if it has not been built (python -m waterorderlib_amd.build)."""
     global _lib
@@ -36,6 +55,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise WolError("libwol.so not found at %s -- build it with `python -m waterorderlib_amd.build` "
                        "(there is no CPU fallback)" % LIB_PATH)
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     L.wol_last_error.restype = C.c_char_p
     L.wol_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
@@ -44,6 +64,7 @@ def load():
     L.wol_ctx_synchronize.argtypes = [_vp]
     L.wol_ctx_set_option.argtypes = [_vp, C.c_char_p, C.c_double]
     L.wol_ctx_kernel_time.argtypes = [_vp, _dp, _lp, C.c_int]
+    L.wol_ctx_get_counter.argtypes = [_vp, C.c_char_p, _lp]
     L.wol_reimage.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp]
     L.wol_near_neighbors.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_double, C.c_double, _vp]
     L.wol_all_near_neighbors.argtypes = [_vp, _vp, C.c_int, _vp, C.c_double, C.c_double, _vp]
@@ -108,6 +129,11 @@ class Context:
 
     def synchronize(self):
         check(load().wol_ctx_synchronize(self.handle))
+
+    def counter(self, key):
+        v = C.c_int64(0)
+        check(load().wol_ctx_get_counter(self.handle, key.encode(), C.byref(v)))
+        return v.value
 
     def kernel_time(self, reset=False):
         ms = C.c_double(0.0)

@@ -1,6 +1,7 @@
 // wol_api.hip -- host side of libwol.so: the C ABI declared in include/wol.h.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared wol_api.hip -o libwol.so
 #include "wol_kernels.hip"
+#include "wol_search_fast.hip"
 
 #include <cmath>
 #include <cstdarg>
@@ -81,7 +82,7 @@ struct wol_ctx {
     int path = 0;
     bool time_kernels = false;
     // workspace
-    DevBuf sorted, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small;
+    DevBuf sorted, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -138,6 +139,43 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
         ms = std::max(ms, std::max(g->lo[k], g->hi[k]));
     }
     g->maxshell = ms;
+
+    // ---- tiling for the filtered kernel (wol_search_fast.hip) ----
+    g->fast_ok = 0;
+    g->sx = g->ry = g->ntx = g->nty = 1;
+    g->ntiles = 0;
+    g->scale = 1.f; g->tmax = 0.f; g->S = 1.0; g->eps_units = 0;
+    if (g->nc[0] >= 3 && g->nc[1] >= 3 && g->nc[2] >= 3) {
+        const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
+        const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
+        const double wpc = std::fmax((double)n / (double)g->ncell, 0.05);
+        g->ntx = (g->nc[0] + 7) / 8;
+        g->sx = (g->nc[0] + g->ntx - 1) / g->ntx;          // <= 8
+        g->ntx = (g->nc[0] + g->sx - 1) / g->sx;
+        double rt = 224.0 / (wpc * g->sx);                  // rows for ~224 waters per tile
+        // keep the expected halo'd tile inside the LDS buffer with 25 % head-room
+        while (rt > 1.0 && 3.0 * (rt + 2.0) * (g->sx + 2) * wpc * 1.25 > (double)WOL_FAST_CAP) rt -= 1.0;
+        int ry = (int)std::floor(rt + 0.5);
+        if (ry < 1) ry = 1;
+        if (ry > WOL_FAST_MAXRY) ry = WOL_FAST_MAXRY;
+        if (ry > g->nc[1]) ry = g->nc[1];
+        g->nty = (g->nc[1] + ry - 1) / ry;
+        g->ry = (g->nc[1] + g->nty - 1) / g->nty;
+        g->nty = (g->nc[1] + g->ry - 1) / g->ry;
+        g->ntiles = g->ntx * g->nty * g->nc[2];
+        g->S = 2097152.0 / (rmax * rmax);                   // 2^21 key units over [0, rmax^2)
+        g->scale = (float)std::sqrt(g->S);
+        g->S = (double)g->scale * (double)g->scale;
+        g->tmax = 8388608.0f + 2097151.0f;
+        // fp32 error of a key: staged coordinates are rounded once (half an ulp at the largest local
+        // magnitude M), differences of two such numbers are exact, the three fmas round to integers
+        const double ext = std::fmax((g->sx + 1) * g->cw[0], std::fmax((g->ry + 1) * g->cw[1], 2.0 * g->cw[2]));
+        const double M = ext * g->scale;
+        const double ulpM = std::ldexp(1.0, (int)std::ceil(std::log2(M)) - 24);
+        const double eps = 2.0 * 1.7320508 * (rmax * g->scale) * ulpM + 1.5;
+        g->eps_units = (int)std::ceil(eps * 1.25) + 2;
+        g->fast_ok = (high >= rmax) ? 1 : 0;
+    }
     return true;
 }
 
@@ -236,6 +274,13 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
                            c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>());
 
+        bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
+        int tiles_max = 0;
+        for (int f = 0; f < F && use_fast; ++f) {
+            if (gh[f].maxshell < 0) continue;
+            if (!gh[f].fast_ok) use_fast = false;
+            tiles_max = std::max(tiles_max, gh[f].ntiles);
+        }
         SearchArgs a;
         a.grids = c->grids.as<FrameGrid>();
         a.sorted = c->sorted.as<double4>();
@@ -253,9 +298,31 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         int grid = (int)std::min<int64_t>(total, 2048);
         if (a.xcd_affine) grid = std::max(8, (grid / 8) * 8);
         std::pair<hipEvent_t, hipEvent_t> ev;
-        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-        hipLaunchKernelGGL(k_search_exact, dim3(grid), dim3(WOL_BLOCK), hist_lds, c->stream, a);
-        if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+        if (use_fast && tiles_max > 0) {
+            WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)F * n));
+            WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
+            HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+            FastArgs fa;
+            fa.grids = a.grids; fa.sorted = a.sorted; fa.cell_start = a.cell_start;
+            fa.n = n; fa.F = F; fa.highsq = highsq; fa.high = high; fa.out = out;
+            fa.tiles_per_frame = tiles_max;
+            fa.xcd_affine = a.xcd_affine;
+            fa.slow_list = c->slow_list.as<unsigned long long>();
+            fa.slow_count = c->slow_count.as<int>();
+            fa.fast_q = (out.ang == nullptr) ? 1 : 0;
+            const int64_t ftotal = (int64_t)F * tiles_max;
+            int fgrid = (int)std::min<int64_t>(ftotal, 256 * 4);
+            if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
+            if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+            hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+            hipLaunchKernelGGL(k_search_exact_list, dim3(256), dim3(WOL_BLOCK), hist_lds, c->stream, a,
+                               c->slow_list.as<unsigned long long>(), c->slow_count.as<int>());
+        } else {
+            if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+            hipLaunchKernelGGL(k_search_exact, dim3(grid), dim3(WOL_BLOCK), hist_lds, c->stream, a);
+            if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+        }
     }
     for (int f : brute_frames) {
         PointsView<T> pv{fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, n};
@@ -298,7 +365,7 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
     if (Fb <= 0) {
         const double per_frame = (double)n * 64.0 + (host ? (double)frame_stride * sizeof(T) : 0.0);
         Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 2.0e9 / per_frame));
-        if (Fb >= 8) Fb = (Fb / 8) * 8;
+        if (Fb >= 8 && Fb < T_frames) Fb = (Fb / 8) * 8;
     }
     Fb = std::min(Fb, T_frames);
 
@@ -424,7 +491,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->sorted, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->slow_list, &c->slow_count};
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
@@ -478,6 +545,22 @@ int wol_ctx_kernel_time(wol_ctx* c, double* ms_total, int64_t* launches, int res
     if (launches) *launches = c->launches;
     if (reset) { c->ms_total = 0.0; c->launches = 0; }
     return WOL_OK;
+}
+
+int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
+    WOL_TRY(check_ctx(c));
+    if (!key || !value) return fail(WOL_ERR_INVALID, "null argument");
+    if (std::string(key) == "slow_waters") {
+        *value = 0;
+        if (c->slow_count.p) {
+            int v = 0;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(&v, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost));
+            *value = v;
+        }
+        return WOL_OK;
+    }
+    return fail(WOL_ERR_INVALID, "unknown counter '%s'", key);
 }
 
 // ---- level 1 ------------------------------------------------------------------------------

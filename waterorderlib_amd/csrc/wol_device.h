@@ -22,8 +22,17 @@ struct FrameGrid {
     int nc[3];         // cells per axis
     int lo[3], hi[3];  // furthest cell offsets ever needed per axis (dedupes small periodic grids)
     int ncell;
-    int maxshell;
+    int maxshell;       // < 0: frame is handled by the all-pairs kernel
     int64_t cell_base;  // offset of this frame's cell_start[] in the batch array
+    // ---- tiling of the filtered (fp32 + exact finish) search kernel ----
+    int fast_ok;        // grid has >= 3 cells per axis and the cutoff covers the guaranteed radius
+    int sx, ry;         // tile = sx cells along x by ry rows along y in one z layer
+    int ntx, nty;       // tiles per axis (ntx*nty*nc[2] tiles per frame)
+    int ntiles;
+    float scale;        // sqrt(S): staged coordinates are multiplied by it so d^2 comes out in key units
+    float tmax;         // 2^23 + 2^21 - 1: saturation of the biased squared distance
+    double S;           // key units per A^2 (2^21 / r2max)
+    int eps_units;      // bound on |fp32 key - exact d^2 * S|
 };
 
 __device__ __forceinline__ double wol_minimg1(double d, double L, double ib) {
