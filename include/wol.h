@@ -49,7 +49,9 @@ const char* wol_last_error(void);
 /* context: device ordinal; owns the stream (unless one is set), workspace and staging buffers */
 int wol_ctx_create(int device, wol_ctx** out);
 int wol_ctx_destroy(wol_ctx* ctx);
-/* run on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+/* run on the caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) instead of the
+ * context's own stream; NULL selects HIP's default (null) stream, which is what torch's default
+ * stream is.  Cheap when the stream is unchanged. */
 int wol_ctx_set_stream(wol_ctx* ctx, void* hip_stream);
 int wol_ctx_synchronize(wol_ctx* ctx);
 /* tunables: "cell_width" (A, default 5.0), "frames_per_batch", "path" (0 auto, 1 force brute-force,

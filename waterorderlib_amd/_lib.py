@@ -125,6 +125,7 @@ class Context:
         check(load().wol_ctx_set_option(self.handle, key.encode(), float(value)))
 
     def set_stream(self, stream_ptr):
+        """stream_ptr: hipStream_t as an int; 0/None = HIP's default stream (torch's default stream)"""
         check(load().wol_ctx_set_stream(self.handle, _vp(stream_ptr) if stream_ptr else None))
 
     def synchronize(self):

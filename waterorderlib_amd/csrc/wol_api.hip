@@ -82,7 +82,7 @@ struct wol_ctx {
     int path = 0;
     bool time_kernels = false;
     // workspace
-    DevBuf sorted, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count;
+    DevBuf sorted, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count, prop, prop_key;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -301,6 +301,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         if (use_fast && tiles_max > 0) {
             WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)F * n));
             WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
+            WOL_TRY(c->prop.ensure(sizeof(int4) * (size_t)F * n));
+            WOL_TRY(c->prop_key.ensure(sizeof(int) * (size_t)F * n));
             HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
             FastArgs fa;
             fa.grids = a.grids; fa.sorted = a.sorted; fa.cell_start = a.cell_start;
@@ -310,12 +312,17 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             fa.slow_list = c->slow_list.as<unsigned long long>();
             fa.slow_count = c->slow_count.as<int>();
             fa.fast_q = (out.ang == nullptr) ? 1 : 0;
+            fa.prop = c->prop.as<int4>();
+            fa.prop_key = c->prop_key.as<int>();
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = (int)std::min<int64_t>(ftotal, 256 * 4);
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-            hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_BLOCK), 0, c->stream, fa);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+            const int64_t wtotal = (int64_t)F * n;
+            const int ggrid = (int)std::min<int64_t>((wtotal + WOL_BLOCK - 1) / WOL_BLOCK, 256 * 8);
+            hipLaunchKernelGGL(k_finish_fast, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             hipLaunchKernelGGL(k_search_exact_list, dim3(256), dim3(WOL_BLOCK), hist_lds, c->stream, a,
                                c->slow_list.as<unsigned long long>(), c->slow_count.as<int>());
         } else {
@@ -491,7 +498,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->sorted, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->slow_list, &c->slow_count};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key};
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
@@ -502,14 +509,11 @@ int wol_ctx_destroy(wol_ctx* c) {
 
 int wol_ctx_set_stream(wol_ctx* c, void* hip_stream) {
     WOL_TRY(check_ctx(c));
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);  // NULL = HIP's default (null) stream
+    if (s == c->stream && !c->own_stream) return WOL_OK;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
-    if (hip_stream) {
-        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
-    } else {
-        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
-    }
+    c->stream = s;
     return WOL_OK;
 }
 

@@ -37,6 +37,8 @@ struct FastArgs {
     unsigned long long* slow_list;  // (frame << 32 | sorted slot) of waters left to the exact kernel
     int* slow_count;
     int fast_q;             // 1: q straight from the cosines (no acos/deg/cos round trip); needs out.ang == null
+    int4* prop;             // [F][n] by sorted slot: sorted slots of the four proposed neighbours
+    int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
 };
 
 __device__ __forceinline__ bool wol_fast_tile_of(const FastArgs& a, int it, int* frame, int* tile) {
@@ -69,8 +71,10 @@ template <bool CENTRE>
 __device__ __forceinline__ void wol_fast_span(const float4* __restrict__ ent, int b, int e, float xi, float yi,
                                               float zi, int self_e, float tmax, unsigned& k0, unsigned& k1,
                                               unsigned& k2, unsigned& k3, unsigned& k4) {
+    float4 nxt = ent[b];  // software prefetch: the next candidate is in flight while this one is ranked
     for (int j = b; j < e; ++j) {
-        const float4 c = ent[j];
+        const float4 c = nxt;
+        nxt = ent[j + 1];  // ent has head-room past the last staged entry
         const float dx = c.x - xi, dy = c.y - yi, dz = c.z - zi;
         float t = __builtin_fmaf(dx, dx, 8388608.0f);  // + 2^23: the mantissa becomes the integer d2
         t = __builtin_fmaf(dy, dy, t);
@@ -145,19 +149,18 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// kernel 1: proposal.  Small register footprint (no fp64), occupancy limited by LDS only.
+// Writes per water (indexed by its slot in the sorted array) the sorted slots of the four proposed
+// neighbours and the 4th key (or -1 when the proposal cannot be certified by keys alone).
+// ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_search_fast(FastArgs a) {
-    extern __shared__ int lds_hist[];
-    __shared__ float4 ent[WOL_FAST_CAP];
+    __shared__ float4 ent[WOL_FAST_CAP + 1];
     __shared__ unsigned char ent_k[WOL_FAST_CAP];
     __shared__ int cellpos[WOL_FAST_MAXROWS * WOL_CP];
     __shared__ int rowsum[WOL_FAST_MAXROWS];
     __shared__ int qstart[WOL_FAST_MAXRY + 2];
-
-    int* lds_qh = a.out.qhist ? lds_hist : nullptr;
-    int* lds_dh = a.out.dhist ? lds_hist + (a.out.qhist ? a.out.qbins : 0) : nullptr;
-    if (lds_qh) wol_hist_zero(lds_qh, a.out.qbins);
-    if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
     const int tid = threadIdx.x;
 
     for (int it = 0;; ++it) {
@@ -173,16 +176,25 @@ k_search_fast(FastArgs a) {
         const int nrows = 3 * rpl, ncr = sxe + 2, ntab = nrows * ncr;
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
         const int* __restrict__ cs = a.cell_start + g.cell_base;
+        const int64_t frame_off = (int64_t)f * a.n;
 
         __syncthreads();  // the previous tile is done with the LDS tables
-        // ---- phase 1: population of every staged cell ----
-        for (int i = tid; i < ntab; i += WOL_BLOCK) {
-            const int r = i / ncr, k = i - r * ncr;
-            const int zi = r / rpl, yi = r - zi * rpl;
-            const int gz = wol_wrap_cell(cz + zi - 1, nz), gy = wol_wrap_cell(y0 + yi - 1, ny);
-            const int gx = wol_wrap_cell(x0 + k - 1, nx);
-            const int cell = (gz * ny + gy) * nx + gx;
-            cellpos[r * WOL_CP + k] = cs[cell + 1] - cs[cell];
+        // ---- phase 1: population of every staged cell (kept in registers for phase 3) ----
+        int c_src[4], c_cnt[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int i = tid + m * WOL_BLOCK;
+            c_src[m] = 0; c_cnt[m] = 0;
+            if (i < ntab) {
+                const int r = i / ncr, k = i - r * ncr;
+                const int zi = r / rpl, yi = r - zi * rpl;
+                const int gz = wol_wrap_cell(cz + zi - 1, nz), gy = wol_wrap_cell(y0 + yi - 1, ny);
+                const int gx = wol_wrap_cell(x0 + k - 1, nx);
+                const int cell = (gz * ny + gy) * nx + gx;
+                c_src[m] = cs[cell];
+                c_cnt[m] = cs[cell + 1] - c_src[m];
+                cellpos[r * WOL_CP + k] = c_cnt[m];
+            }
         }
         __syncthreads();
         // ---- phase 2: exclusive scan, row-major over (row, cell) ----
@@ -213,26 +225,38 @@ k_search_fast(FastArgs a) {
         const bool overflow = total > WOL_FAST_CAP;
         // ---- phase 3: stage the halo'd tile as scaled fp32, images shifted into the local frame ----
         if (!overflow) {
-            for (int i = tid; i < ntab; i += WOL_BLOCK) {
+            const double fx = g.cw[0] * (double)g.scale, fy = g.cw[1] * (double)g.scale, fz = g.cw[2] * (double)g.scale;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int i = tid + m * WOL_BLOCK;
+                if (i >= ntab) break;
                 const int r = i / ncr, k = i - r * ncr;
                 const int zi = r / rpl, yi = r - zi * rpl;
                 const int uz = cz + zi - 1, uy = y0 + yi - 1, ux = x0 + k - 1;  // unwrapped cell coordinates
-                const int gz = wol_wrap_cell(uz, nz), gy = wol_wrap_cell(uy, ny), gx = wol_wrap_cell(ux, nx);
-                const int cell = (gz * ny + gy) * nx + gx;
-                const int src = cs[cell], cnt = cs[cell + 1] - src;
-                const int dst = cellpos[r * WOL_CP + k];
                 // offsets (in cells) that move a wrapped coordinate into the tile frame
-                const double ox = (double)(ux - gx - x0), oy = (double)(uy - gy - y0), oz = (double)(uz - gz - cz);
-                for (int e = 0; e < cnt; ++e) {
-                    const double4 v = sp[src + e];
-                    double u;
-                    float4 o;
-                    u = v.x * g.box.ib[0]; u -= floor(u); o.x = (float)((u * (double)nx + ox) * g.cw[0] * (double)g.scale);
-                    u = v.y * g.box.ib[1]; u -= floor(u); o.y = (float)((u * (double)ny + oy) * g.cw[1] * (double)g.scale);
-                    u = v.z * g.box.ib[2]; u -= floor(u); o.z = (float)((u * (double)nz + oz) * g.cw[2] * (double)g.scale);
-                    o.w = __int_as_float(src + e);
-                    ent[dst + e] = o;
-                    ent_k[dst + e] = (unsigned char)k;
+                const double ox = (double)(ux - wol_wrap_cell(ux, nx) - x0);
+                const double oy = (double)(uy - wol_wrap_cell(uy, ny) - y0);
+                const double oz = (double)(uz - wol_wrap_cell(uz, nz) - cz);
+                const int src = c_src[m], cnt = c_cnt[m];
+                const int dst = cellpos[r * WOL_CP + k];
+                for (int e0 = 0; e0 < cnt; e0 += 4) {
+                    double4 v[4];
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4)  // issue the loads together, then convert
+                        if (e0 + u4 < cnt) v[u4] = sp[src + e0 + u4];
+#pragma unroll
+                    for (int u4 = 0; u4 < 4; ++u4) {
+                        if (e0 + u4 < cnt) {
+                            double u;
+                            float4 o;
+                            u = v[u4].x * g.box.ib[0]; u -= floor(u); o.x = (float)((u * (double)nx + ox) * fx);
+                            u = v[u4].y * g.box.ib[1]; u -= floor(u); o.y = (float)((u * (double)ny + oy) * fy);
+                            u = v[u4].z * g.box.ib[2]; u -= floor(u); o.z = (float)((u * (double)nz + oz) * fz);
+                            o.w = __int_as_float(src + e0 + u4);
+                            ent[dst + e0 + u4] = o;
+                            ent_k[dst + e0 + u4] = (unsigned char)k;
+                        }
+                    }
                 }
             }
         }
@@ -262,12 +286,14 @@ k_search_fast(FastArgs a) {
             while (ly + 1 < re && qstart[ly + 1] <= qi) ++ly;
             const int rq = rpl + ly + 1;
             const int self_e = cellpos[rq * WOL_CP + 1] + (qi - qstart[ly]);
-            bool slow = overflow;
-            int self_slot;
-            unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
+            // slot of this water in the sorted array: the tile's cells of a row are contiguous there
+            const int self_slot = cs[(cz * ny + (y0 + ly)) * nx + x0] + (qi - qstart[ly]);
+            int4 prop;
+            prop.x = prop.y = prop.z = prop.w = 0;
+            int kd3 = -1;
             if (!overflow) {
+                unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
                 const float4 me = ent[self_e];
-                self_slot = __float_as_int(me.w);
                 const int lx = (int)ent_k[self_e] - 1;  // 0-based cell of the water inside the tile
 #pragma unroll
                 for (int dzi = 0; dzi < 3; ++dzi) {
@@ -281,70 +307,97 @@ k_search_fast(FastArgs a) {
                             wol_fast_span<false>(ent, b, e, me.x, me.y, me.z, self_e, g.tmax, k0, k1, k2, k3, k4);
                     }
                 }
-            } else {
-                // tile did not fit: recover the slot of this water without the staged copy
-                const int gy = y0 + ly;
-                const int cell0 = (cz * ny + gy) * nx + x0;
-                self_slot = cs[cell0] + (qi - qstart[ly]);
-            }
-            const int64_t frame_off = (int64_t)f * a.n;
-            if (!slow) {
                 // the proposal stands only if it is separated from the 5th candidate by more than the
                 // fp32 error and is not saturated
                 const unsigned d3 = k3 >> 11, d4 = k4 >> 11;
                 const unsigned sat = (1u << 21) - 1u - (unsigned)g.eps_units;
-                if (k3 == 0xFFFFFFFFu || d3 >= sat || d4 - d3 <= 2u * (unsigned)g.eps_units) slow = true;
+                if (k3 != 0xFFFFFFFFu && d3 < sat && d4 - d3 > 2u * (unsigned)g.eps_units) {
+                    prop.x = __float_as_int(ent[k0 & 0x7FFu].w); prop.y = __float_as_int(ent[k1 & 0x7FFu].w);
+                    prop.z = __float_as_int(ent[k2 & 0x7FFu].w); prop.w = __float_as_int(ent[k3 & 0x7FFu].w);
+                    kd3 = (int)d3;
+                }
             }
-            if (!slow) {
-                const double4 mev = sp[self_slot];
-                const double c[3] = {mev.x, mev.y, mev.z};
-                const int s0 = __float_as_int(ent[k0 & 0x7FFu].w), s1 = __float_as_int(ent[k1 & 0x7FFu].w);
-                const int s2 = __float_as_int(ent[k2 & 0x7FFu].w), s3 = __float_as_int(ent[k3 & 0x7FFu].w);
-                const double4 n0 = sp[s0], n1 = sp[s1], n2 = sp[s2], n3 = sp[s3];
-                Top4 t;
-                top4_init(t);
-                double dist;
-                bool in_mask, all_in = true;
-                const double inf = __builtin_huge_val();
-                if (wol_eval_pair(c, n0.x, n0.y, n0.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
-                    top4_insert(t, dist, (int)__double_as_longlong(n0.w), s0);
-                all_in = all_in && in_mask;
-                if (wol_eval_pair(c, n1.x, n1.y, n1.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
-                    top4_insert(t, dist, (int)__double_as_longlong(n1.w), s1);
-                all_in = all_in && in_mask;
-                if (wol_eval_pair(c, n2.x, n2.y, n2.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
-                    top4_insert(t, dist, (int)__double_as_longlong(n2.w), s2);
-                all_in = all_in && in_mask;
-                if (wol_eval_pair(c, n3.x, n3.y, n3.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
-                    top4_insert(t, dist, (int)__double_as_longlong(n3.w), s3);
-                all_in = all_in && in_mask;
-                // radius the 27-cell stencil guarantees to be complete around this water
-                double rg = __builtin_huge_val();
+            a.prop[frame_off + self_slot] = prop;
+            a.prop_key[frame_off + self_slot] = kd3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel 2: certification + epilogue, one lane per water in sorted order.  Re-evaluates the four
+// proposed neighbours from the fp64 coordinates with the reference's arithmetic, accepts when the
+// 4th distance is inside the radius the 27-cell stencil guarantees (and agrees with the fp32 key),
+// computes angles / q / histograms; everything else goes to the exact list.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_finish_fast(FastArgs a) {
+    extern __shared__ int lds_hist[];
+    int* lds_qh = a.out.qhist ? lds_hist : nullptr;
+    int* lds_dh = a.out.dhist ? lds_hist + (a.out.qhist ? a.out.qbins : 0) : nullptr;
+    if (lds_qh) wol_hist_zero(lds_qh, a.out.qbins);
+    if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
+    __syncthreads();
+    const int64_t total = (int64_t)a.F * a.n;
+    for (int64_t w = (int64_t)blockIdx.x * WOL_BLOCK + threadIdx.x; w < total; w += (int64_t)gridDim.x * WOL_BLOCK) {
+        const int f = (int)(w / a.n);
+        const int s = (int)(w - (int64_t)f * a.n);
+        const FrameGrid& g = a.grids[f];
+        if (g.maxshell < 0) continue;  // all-pairs frame
+        const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+        const int kd3 = a.prop_key[w];
+        bool slow = kd3 < 0;
+        if (!slow) {
+            const int4 pr = a.prop[w];
+            const double4 mev = sp[s];
+            const double c[3] = {mev.x, mev.y, mev.z};
+            const double4 n0 = sp[pr.x], n1 = sp[pr.y], n2 = sp[pr.z], n3 = sp[pr.w];
+            Top4 t;
+            top4_init(t);
+            double dist;
+            bool in_mask, all_in = true;
+            const double inf = __builtin_huge_val();
+            if (wol_eval_pair(c, n0.x, n0.y, n0.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
+                top4_insert(t, dist, (int)__double_as_longlong(n0.w), 0);
+            all_in = all_in && in_mask;
+            if (wol_eval_pair(c, n1.x, n1.y, n1.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
+                top4_insert(t, dist, (int)__double_as_longlong(n1.w), 1);
+            all_in = all_in && in_mask;
+            if (wol_eval_pair(c, n2.x, n2.y, n2.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
+                top4_insert(t, dist, (int)__double_as_longlong(n2.w), 2);
+            all_in = all_in && in_mask;
+            if (wol_eval_pair(c, n3.x, n3.y, n3.z, g.box, 0.0, a.highsq, inf, &dist, &in_mask))
+                top4_insert(t, dist, (int)__double_as_longlong(n3.w), 3);
+            all_in = all_in && in_mask;
+            // radius the 27-cell stencil guarantees to be complete around this water
+            double rg = __builtin_huge_val();
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    double fr;
-                    (void)wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr);
-                    rg = fmin(rg, g.cw[k] + fmin(fr, 1.0 - fr) * g.cw[k]);
-                }
-                rg -= 1e-6;
-                // the exact 4th key must also agree with the fp32 proposal (guards the error bound itself)
-                const double d3s = (t.d3 * t.d3) * g.S;
-                const double k3s = (double)(k3 >> 11);
-                if (!all_in || t.n != 4 || !(t.d3 <= rg) || fabs(d3s - k3s) > (double)g.eps_units) {
-                    slow = true;
-                } else {
-                    const double4 m0 = sp[t.s0], m1 = sp[t.s1], m2 = sp[t.s2], m3 = sp[t.s3];
-                    const double N0[3] = {m0.x, m0.y, m0.z}, N1[3] = {m1.x, m1.y, m1.z};
-                    const double N2[3] = {m2.x, m2.y, m2.z}, N3[3] = {m3.x, m3.y, m3.z};
-                    const int64_t orow = frame_off + (int)__double_as_longlong(mev.w);
-                    if (a.fast_q) wol_finish_water_fastq(c, t, N0, N1, N2, N3, g.box, a.out, orow, lds_qh, lds_dh);
-                    else wol_finish_water(c, t, N0, N1, N2, N3, g.box, a.out, orow, lds_qh, lds_dh);
-                }
+            for (int k = 0; k < 3; ++k) {
+                double fr;
+                (void)wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr);
+                rg = fmin(rg, g.cw[k] + fmin(fr, 1.0 - fr) * g.cw[k]);
             }
-            if (slow) {
-                const int pos = atomicAdd(a.slow_count, 1);
-                a.slow_list[pos] = ((unsigned long long)f << 32) | (unsigned)self_slot;
+            rg -= 1e-6;
+            // the exact 4th key must also agree with the fp32 proposal (guards the error bound itself)
+            const double d3s = (t.d3 * t.d3) * g.S;
+            if (!all_in || t.n != 4 || !(t.d3 <= rg) || fabs(d3s - (double)kd3) > (double)g.eps_units) {
+                slow = true;
+            } else {
+                // neighbours in exact rank order (t.s* = position 0..3 in the proposal)
+                double N[4][3];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int which = (k == 0) ? t.s0 : (k == 1) ? t.s1 : (k == 2) ? t.s2 : t.s3;
+                    const double4 m = (which == 0) ? n0 : (which == 1) ? n1 : (which == 2) ? n2 : n3;
+                    N[k][0] = m.x; N[k][1] = m.y; N[k][2] = m.z;
+                }
+                const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
+                if (a.fast_q) wol_finish_water_fastq(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, lds_qh, lds_dh);
+                else wol_finish_water(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, lds_qh, lds_dh);
             }
+        }
+        if (slow) {
+            const int pos = atomicAdd(a.slow_count, 1);
+            a.slow_list[pos] = ((unsigned long long)f << 32) | (unsigned)s;
         }
     }
     __syncthreads();
