@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwol.so")
+LIB_PATH = os.environ.get("WOL_LIB_PATH") or os.path.join(_HERE, "libwol.so")  # env override: tuning builds
 
 MEM_HOST, MEM_DEVICE = 0, 1
 

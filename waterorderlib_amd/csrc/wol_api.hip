@@ -74,6 +74,7 @@ struct PinBuf {
 
 struct wol_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // options
@@ -82,7 +83,7 @@ struct wol_ctx {
     int path = 0;
     bool time_kernels = false;
     // workspace
-    DevBuf sorted, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count, prop, prop_key;
+    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -149,34 +150,59 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
         const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
         const double wpc = std::fmax((double)n / (double)g->ncell, 0.05);
-        g->ntx = (g->nc[0] + 7) / 8;
-        g->sx = (g->nc[0] + g->ntx - 1) / g->ntx;          // <= 8
-        g->ntx = (g->nc[0] + g->sx - 1) / g->sx;
-        double rt = 224.0 / (wpc * g->sx);                  // rows for ~224 waters per tile
-        // keep the expected halo'd tile inside the LDS buffer with 25 % head-room
-        while (rt > 1.0 && 3.0 * (rt + 2.0) * (g->sx + 2) * wpc * 1.25 > (double)WOL_FAST_CAP) rt -= 1.0;
-        int ry = (int)std::floor(rt + 0.5);
-        if (ry < 1) ry = 1;
-        if (ry > WOL_FAST_MAXRY) ry = WOL_FAST_MAXRY;
-        if (ry > g->nc[1]) ry = g->nc[1];
-        g->nty = (g->nc[1] + ry - 1) / ry;
-        g->ry = (g->nc[1] + g->nty - 1) / g->nty;
-        g->nty = (g->nc[1] + g->ry - 1) / g->ry;
+        // tile = sx x ry cells of one z layer: as many waters as fit one sweep of the block (one lane
+        // per water, ~7 % head-room) while the halo'd tile (3 layers of (ry+2) x (sx+2) cells, each
+        // padded to an even count, +15 %) fits the LDS pair buffer; all tiles of a frame equal-sized
+        double best = -1.0;
+        g->sx = 1; g->ry = 1; g->ntx = g->nc[0]; g->nty = g->nc[1];
+        for (int ntx = 1; ntx <= g->nc[0]; ++ntx) {
+            const int sx = (g->nc[0] + ntx - 1) / ntx;
+            if (sx > WOL_FAST_MAXSX) continue;
+            if ((g->nc[0] + sx - 1) / sx != ntx) continue;
+            for (int nty = 1; nty <= g->nc[1]; ++nty) {
+                const int ry = (g->nc[1] + nty - 1) / nty;
+                if (ry > WOL_FAST_MAXRY || (g->nc[1] + ry - 1) / ry != nty) continue;
+                const double q = sx * ry * wpc;
+                if (q > (double)WOL_FAST_TARGET && !(sx == 1 && ry == 1)) continue;
+                if (3.0 * (ry + 2) * (sx + 2) * (wpc + 0.5) * 1.15 > 2.0 * WOL_FAST_CAPP) continue;
+                // prefer full sweeps; among equals the squarer tile (smaller halo)
+                const double score = q - 0.01 * std::abs(sx - ry);
+                if (score > best) { best = score; g->sx = sx; g->ry = ry; g->ntx = ntx; g->nty = nty; }
+            }
+        }
         g->ntiles = g->ntx * g->nty * g->nc[2];
-        g->S = 2097152.0 / (rmax * rmax);                   // 2^21 key units over [0, rmax^2)
+        const double kunits = std::ldexp(1.0, 32 - WOL_ID_BITS);
+        g->S = kunits / (rmax * rmax);                      // key units over [0, rmax^2)
         g->scale = (float)std::sqrt(g->S);
         g->S = (double)g->scale * (double)g->scale;
-        g->tmax = 8388608.0f + 2097151.0f;
+        g->tmax = 8388608.0f + (float)(kunits - 1.0);
         // fp32 error of a key: staged coordinates are rounded once (half an ulp at the largest local
         // magnitude M), differences of two such numbers are exact, the three fmas round to integers
-        const double ext = std::fmax((g->sx + 1) * g->cw[0], std::fmax((g->ry + 1) * g->cw[1], 2.0 * g->cw[2]));
+        // (x is kept relative to the box origin until it is staged, so M is the box length there)
+        const double ext = std::fmax(box[0] + g->cw[0], std::fmax((g->ry + 2) * g->cw[1], 3.0 * g->cw[2]));
         const double M = ext * g->scale;
         const double ulpM = std::ldexp(1.0, (int)std::ceil(std::log2(M)) - 24);
-        const double eps = 2.0 * 1.7320508 * (rmax * g->scale) * ulpM + 1.5;
+        const double eps = 2.0 * 1.7320508 * (rmax * g->scale) * (2.0 * ulpM) + 1.5;
         g->eps_units = (int)std::ceil(eps * 1.25) + 2;
         g->fast_ok = (high >= rmax) ? 1 : 0;
     }
     return true;
+}
+
+// grid of a persistent (grid-stride) kernel: one round of resident blocks (blocks/CU from the
+// occupancy query).  None of these kernels synchronises across blocks, so a block that turns out
+// not to be co-resident merely starts late.
+template <typename K>
+int resident_grid(wol_ctx* c, K kernel, int block, size_t dyn_lds, int64_t work_items, int* grid, int margin = 0) {
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, dyn_lds));
+    per_cu -= margin;
+    if (per_cu < 1) per_cu = 1;
+    int64_t g = (int64_t)per_cu * c->num_cus;
+    if (g > work_items) g = work_items;
+    if (g < 1) g = 1;
+    *grid = (int)g;
+    return WOL_OK;
 }
 
 int begin_timing(wol_ctx* c, std::pair<hipEvent_t, hipEvent_t>* ev) {
@@ -267,13 +293,6 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
         c->grid_copy_pending = true;
         HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)cell_total, c->stream));
-        const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
-        hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
-        hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
-        hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>());
-
         bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
         int tiles_max = 0;
         for (int f = 0; f < F && use_fast; ++f) {
@@ -281,6 +300,19 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             if (!gh[f].fast_ok) use_fast = false;
             tiles_max = std::max(tiles_max, gh[f].ntiles);
         }
+        if (tiles_max == 0) use_fast = false;
+        float4* s32 = nullptr;
+        if (use_fast) {
+            WOL_TRY(c->sorted32.ensure(sizeof(float4) * (size_t)F * n));
+            s32 = c->sorted32.as<float4>();
+        }
+        const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
+        hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
+        hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
+        hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>(), s32);
+
         SearchArgs a;
         a.grids = c->grids.as<FrameGrid>();
         a.sorted = c->sorted.as<double4>();
@@ -295,17 +327,18 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         a.tiles_per_frame = (ns + WOL_BLOCK - 1) / WOL_BLOCK;
         a.xcd_affine = (F >= 8) ? 1 : 0;
         const int64_t total = (int64_t)F * a.tiles_per_frame;
-        int grid = (int)std::min<int64_t>(total, 2048);
+        int grid = 0;
+        WOL_TRY(resident_grid(c, k_search_exact, WOL_BLOCK, hist_lds, total, &grid));
         if (a.xcd_affine) grid = std::max(8, (grid / 8) * 8);
         std::pair<hipEvent_t, hipEvent_t> ev;
-        if (use_fast && tiles_max > 0) {
+        if (use_fast) {
             WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)F * n));
             WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
             WOL_TRY(c->prop.ensure(sizeof(int4) * (size_t)F * n));
             WOL_TRY(c->prop_key.ensure(sizeof(int) * (size_t)F * n));
             HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
             FastArgs fa;
-            fa.grids = a.grids; fa.sorted = a.sorted; fa.cell_start = a.cell_start;
+            fa.grids = a.grids; fa.sorted = a.sorted; fa.sorted32 = s32; fa.cell_start = a.cell_start;
             fa.n = n; fa.F = F; fa.highsq = highsq; fa.high = high; fa.out = out;
             fa.tiles_per_frame = tiles_max;
             fa.xcd_affine = a.xcd_affine;
@@ -314,16 +347,26 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             fa.fast_q = (out.ang == nullptr) ? 1 : 0;
             fa.prop = c->prop.as<int4>();
             fa.prop_key = c->prop_key.as<int>();
+            fa.stamps = nullptr;
+#ifdef WOL_PHASE_STAMPS
+            WOL_TRY(c->stamps.ensure(sizeof(unsigned long long) * 8));
+            fa.stamps = c->stamps.as<unsigned long long>();
+#endif
             const int64_t ftotal = (int64_t)F * tiles_max;
-            int fgrid = (int)std::min<int64_t>(ftotal, 256 * 4);
+            int fgrid = 0;
+            WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-            hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_BLOCK), 0, c->stream, fa);
+            hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
             const int64_t wtotal = (int64_t)F * n;
-            const int ggrid = (int)std::min<int64_t>((wtotal + WOL_BLOCK - 1) / WOL_BLOCK, 256 * 8);
+            int ggrid = 0;
+            WOL_TRY(resident_grid(c, k_finish_fast, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            if (fa.xcd_affine) ggrid = std::max(8, (ggrid / 8) * 8);
             hipLaunchKernelGGL(k_finish_fast, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
-            hipLaunchKernelGGL(k_search_exact_list, dim3(256), dim3(WOL_BLOCK), hist_lds, c->stream, a,
+            int lgrid = 0;
+            WOL_TRY(resident_grid(c, k_search_exact_list, WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
+            hipLaunchKernelGGL(k_search_exact_list, dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
                                c->slow_list.as<unsigned long long>(), c->slow_count.as<int>());
         } else {
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
@@ -484,6 +527,11 @@ int wol_ctx_create(int device, wol_ctx** out) {
     wol_ctx* c = new (std::nothrow) wol_ctx();
     if (!c) return fail(WOL_ERR_NOMEM, "out of host memory");
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->num_cus = prop.multiProcessorCount;
+    }
     hipError_t se = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (se != hipSuccess) { delete c; return fail(WOL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(se)); }
     c->own_stream = true;
@@ -497,8 +545,8 @@ int wol_ctx_destroy(wol_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    DevBuf* bufs[] = {&c->sorted, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key};
+    DevBuf* bufs[] = {&c->sorted, &c->sorted32, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
+                      &c->out_stage, &c->hist_stage, &c->small, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
@@ -564,6 +612,16 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
         }
         return WOL_OK;
     }
+#ifdef WOL_PHASE_STAMPS
+    if (std::string(key).rfind("stamp", 0) == 0 && c->stamps.p) {
+        unsigned long long v[8];
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpy(v, c->stamps.p, sizeof v, hipMemcpyDeviceToHost));
+        *value = (int64_t)v[key[5] - '0'];
+        if (key[6] == 'z') HIP_TRY(hipMemset(c->stamps.p, 0, sizeof v));
+        return WOL_OK;
+    }
+#endif
     return fail(WOL_ERR_INVALID, "unknown counter '%s'", key);
 }
 

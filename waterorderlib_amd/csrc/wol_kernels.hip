@@ -74,18 +74,33 @@ k_cell_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count) {
 template <typename T>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start,
-          const int* __restrict__ cellid, const int* __restrict__ rank, double4* __restrict__ sorted) {
+          const int* __restrict__ cellid, const int* __restrict__ rank, double4* __restrict__ sorted,
+          float4* __restrict__ sorted32) {
     const int f = blockIdx.y;
     const int i = blockIdx.x * WOL_BLOCK + threadIdx.x;
     if (i >= fv.n) return;
     const FrameGrid& g = grids[f];
     const T* p = fv.base + (int64_t)f * fv.frame_stride + (int64_t)i * fv.atom_stride;
     const int64_t o = (int64_t)f * fv.n;
-    const int dst = cell_start[g.cell_base + cellid[o + i]] + rank[o + i];
+    const int cell = cellid[o + i];
+    const int dst = cell_start[g.cell_base + cell] + rank[o + i];
     double4 v;
     v.x = (double)p[0]; v.y = (double)p[1]; v.z = (double)p[2];
     v.w = __longlong_as_double((long long)i);
     sorted[o + dst] = v;
+    if (sorted32) {
+        // fp32 copy for the filtered search, already in key units: x = wrapped coordinate from the box
+        // origin, y and z = position inside the own cell (a staged row has one y and one z cell)
+        const int nx = g.nc[0], ny = g.nc[1];
+        const int cy = (cell / nx) % ny, cz = cell / (nx * ny);
+        double u;
+        float4 w;
+        u = v.x * g.box.ib[0]; u -= floor(u); w.x = (float)(u * (double)nx * g.cw[0] * (double)g.scale);
+        u = v.y * g.box.ib[1]; u -= floor(u); w.y = (float)((u * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
+        u = v.z * g.box.ib[2]; u -= floor(u); w.z = (float)((u * (double)g.nc[2] - (double)cz) * g.cw[2] * (double)g.scale);
+        w.w = 0.f;
+        sorted32[o + dst] = w;
+    }
 }
 
 // =============================================================================================

@@ -19,15 +19,41 @@
 // the exact path by construction; the filter only decides who needs it.
 #pragma once
 
-#define WOL_FAST_CAP 1536     // staged candidates per tile
-#define WOL_FAST_MAXROWS 64   // 3*(ry+2) <= 64
-#define WOL_CP 13             // row stride of the cell-position table: sx + 3 <= 13
-#define WOL_FAST_MAXRY 19
-#define WOL_FAST_MAXSX 10
+// Geometry of the proposal kernel (overridable at build time for tuning runs).
+#ifndef WOL_FAST_BLOCK
+#define WOL_FAST_BLOCK 512    // waves of a block share one staged tile; each sweeps one batch of 64 waters
+#endif
+#ifndef WOL_FAST_CAPP
+#define WOL_FAST_CAPP 1280    // staged PAIRS per tile (cells are padded to an even count)
+#endif
+#define WOL_FAST_TARGET ((WOL_FAST_BLOCK * 93) / 100)  // waters per tile aimed at (one lane each)
+#define WOL_FAST_PADP 40      // head-room (pairs) incl. the dummy pair
+#define WOL_FAST_MAXROWS 96   // 3*(ry+2) <= 96
+#define WOL_FAST_MAXRY 30
+#define WOL_FAST_MAXSX 12
+#define WOL_CP 16             // row stride of the cell tables: sx + 3 <= 15
+#define WOL_FAST_MAXCELL 20   // a cell with more waters sends its tile to the exact path (span <= 64 entries)
+#define WOL_ID_BITS 12        // key = d2 (20 bits) << 12 | entry index in the staged tile
+
+// Diagnostic build only (-DWOL_PHASE_STAMPS): per-phase shader-clock totals of k_search_fast, added
+// by lane 0 of every block into a buffer that nothing else reads.  The product build has no stamps.
+#ifdef WOL_PHASE_STAMPS
+#define WOL_STAMP(slot)                                                                 \
+    do {                                                                                \
+        if (threadIdx.x == 0) {                                                         \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
+            atomicAdd(&a.stamps[slot], now_ - stamp_prev_);                             \
+            stamp_prev_ = now_;                                                         \
+        }                                                                               \
+    } while (0)
+#else
+#define WOL_STAMP(slot) do { } while (0)
+#endif
 
 struct FastArgs {
     const FrameGrid* grids;
     const double4* sorted;  // [F][n]
+    const float4* sorted32; // [F][n] fp32 copy in key units (k_scatter)
     const int* cell_start;
     int n, F;
     double highsq, high;
@@ -39,55 +65,64 @@ struct FastArgs {
     int fast_q;             // 1: q straight from the cosines (no acos/deg/cos round trip); needs out.ang == null
     int4* prop;             // [F][n] by sorted slot: sorted slots of the four proposed neighbours
     int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
+    unsigned long long* stamps;  // diagnostic builds only
 };
 
-__device__ __forceinline__ bool wol_fast_tile_of(const FastArgs& a, int it, int* frame, int* tile) {
-    if (a.xcd_affine) {
-        const int xcd = blockIdx.x & 7;
-        const int k = blockIdx.x >> 3;
-        const int K = gridDim.x >> 3;
-        const int64_t m = (int64_t)it * K + k;
-        const int f = (int)(m / a.tiles_per_frame) * 8 + xcd;
-        if (f >= a.F) return false;
-        *frame = f;
-        *tile = (int)(m % a.tiles_per_frame);
-        return true;
-    }
-    const int64_t m = (int64_t)it * gridDim.x + blockIdx.x;
-    if (m >= (int64_t)a.F * a.tiles_per_frame) return false;
-    *frame = (int)(m / a.tiles_per_frame);
-    *tile = (int)(m % a.tiles_per_frame);
-    return true;
+// sorted insert of `key` into k0 <= k1 <= ... <= k4 (the largest falls off): new k_i is the median of
+// (old k_{i-1}, old k_i, key).  Done from the top down so every op still sees the old lower
+// neighbour and the update is in place: one v_min_u32 + four v_med3_u32, no moves.
+__device__ __forceinline__ void wol_top5_insert(unsigned key, unsigned& k0, unsigned& k1, unsigned& k2,
+                                                unsigned& k3, unsigned& k4) {
+    // one asm statement with all five keys tied in place: the register allocator then keeps them in
+    // fixed registers across the loop instead of copying around per-instruction constraints
+    asm("v_med3_u32 %4, %3, %4, %5\n\t"
+        "v_med3_u32 %3, %2, %3, %5\n\t"
+        "v_med3_u32 %2, %1, %2, %5\n\t"
+        "v_med3_u32 %1, %0, %1, %5\n\t"
+        "v_min_u32 %0, %0, %5"
+        : "+v"(k0), "+v"(k1), "+v"(k2), "+v"(k3), "+v"(k4)
+        : "v"(key));
 }
 
-__device__ __forceinline__ unsigned wol_med3u(unsigned a, unsigned b, unsigned c) {
-    unsigned r;  // median of three unsigned ints in one VALU op (no clang builtin for the integer form)
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+typedef float wol_f2 __attribute__((ext_vector_type(2)));
 
-// one LDS span of candidates against the lane's water; keys k0 <= ... <= k4 are the running top-5
+// One span of candidate PAIRS against the lane's water.  A staged pair is two float4:
+// (x0, x1, y0, y1) and (z0, z1, id0, id1); the three differences and the three fused multiply-adds
+// are packed (v_pk_add_f32 / v_pk_fma_f32: two candidates per instruction).  The +2^23 bias makes the
+// float's mantissa the integer squared distance in key units; it is saturated and shifted above the
+// entry id.  The trip count is wave-uniform (vote); a lane past the end of its own span is pointed
+// at the tile's dummy pair, whose far-away coordinates saturate, so no per-element masks are needed.
 template <bool CENTRE>
-__device__ __forceinline__ void wol_fast_span(const float4* __restrict__ ent, int b, int e, float xi, float yi,
-                                              float zi, int self_e, float tmax, unsigned& k0, unsigned& k1,
-                                              unsigned& k2, unsigned& k3, unsigned& k4) {
-    float4 nxt = ent[b];  // software prefetch: the next candidate is in flight while this one is ranked
-    for (int j = b; j < e; ++j) {
-        const float4 c = nxt;
-        nxt = ent[j + 1];  // ent has head-room past the last staged entry
-        const float dx = c.x - xi, dy = c.y - yi, dz = c.z - zi;
-        float t = __builtin_fmaf(dx, dx, 8388608.0f);  // + 2^23: the mantissa becomes the integer d2
-        t = __builtin_fmaf(dy, dy, t);
-        t = __builtin_fmaf(dz, dz, t);
-        t = fminf(t, tmax);
-        unsigned key = (__float_as_uint(t) << 11) | (unsigned)j;
-        if (CENTRE) key = (j == self_e) ? 0xFFFFFFFFu : key;
-        const unsigned n0 = min(k0, key);
-        const unsigned n1 = wol_med3u(k0, k1, key);
-        const unsigned n2 = wol_med3u(k1, k2, key);
-        const unsigned n3 = wol_med3u(k2, k3, key);
-        const unsigned n4 = wol_med3u(k3, k4, key);
-        k0 = n0; k1 = n1; k2 = n2; k3 = n3; k4 = n4;
+__device__ __forceinline__ void wol_fast_span(const char* __restrict__ rec_bytes, int pb, int np, int dummy_off,
+                                              wol_f2 xi, wol_f2 yi, wol_f2 zi, unsigned self_id,
+                                              unsigned tmaxbits, unsigned& k0, unsigned& k1, unsigned& k2,
+                                              unsigned& k3, unsigned& k4) {
+    const wol_f2 bias = {8388608.0f, 8388608.0f};
+    int off = pb * 32;              // byte offset of the lane's current pair record
+    const int end = (pb + np) * 32;
+    // wave-uniform trip count: the longest span among the 64 lanes (butterfly max, then scalar)
+    int tmax_np = np;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) tmax_np = max(tmax_np, __shfl_xor(tmax_np, sh, 64));
+    const int T = __builtin_amdgcn_readfirstlane(tmax_np);
+    for (int t = 0; t < T; ++t, off += 32) {
+        const bool v = off < end;
+        const int o = v ? off : dummy_off;
+        const float4 a = *reinterpret_cast<const float4*>(rec_bytes + o);
+        const float4 b = *reinterpret_cast<const float4*>(rec_bytes + o + 16);
+        const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
+        wol_f2 tt = __builtin_elementwise_fma(dx, dx, bias);
+        tt = __builtin_elementwise_fma(dy, dy, tt);
+        tt = __builtin_elementwise_fma(dz, dz, tt);
+        const unsigned id0 = __float_as_uint(b.z), id1 = __float_as_uint(b.w);
+        unsigned key0 = (min(__float_as_uint(tt.x), tmaxbits) << WOL_ID_BITS) | id0;
+        unsigned key1 = (min(__float_as_uint(tt.y), tmaxbits) << WOL_ID_BITS) | id1;
+        if (CENTRE) {
+            key0 = (id0 == self_id) ? 0xFFFFFFFFu : key0;
+            key1 = (id1 == self_id) ? 0xFFFFFFFFu : key1;
+        }
+        wol_top5_insert(key0, k0, k1, k2, k3, k4);
+        wol_top5_insert(key1, k0, k1, k2, k3, k4);
     }
 }
 
@@ -154,172 +189,239 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
 // Writes per water (indexed by its slot in the sorted array) the sorted slots of the four proposed
 // neighbours and the 4th key (or -1 when the proposal cannot be certified by keys alone).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WOL_BLOCK)
+__global__ void __launch_bounds__(WOL_FAST_BLOCK)
 k_search_fast(FastArgs a) {
-    __shared__ float4 ent[WOL_FAST_CAP + 1];
-    __shared__ unsigned char ent_k[WOL_FAST_CAP];
-    __shared__ int cellpos[WOL_FAST_MAXROWS * WOL_CP];
-    __shared__ int rowsum[WOL_FAST_MAXROWS];
-    __shared__ int qstart[WOL_FAST_MAXRY + 2];
+    __shared__ float4 rec[2 * (WOL_FAST_CAPP + WOL_FAST_PADP)];     // pair records
+    __shared__ int slot[2 * WOL_FAST_CAPP];                         // entry -> slot in the sorted array
+    __shared__ int cellsrc[WOL_FAST_MAXROWS * WOL_CP];              // staged cell -> first slot
+    __shared__ unsigned short cellpos[WOL_FAST_MAXROWS * WOL_CP];   // staged cell -> first entry (even)
+    __shared__ unsigned char cellcnt[WOL_FAST_MAXROWS * WOL_CP];    // staged cell -> waters in it
+    __shared__ int rowlen[WOL_FAST_MAXROWS];
+    __shared__ int qrow[WOL_FAST_MAXRY + 2];                        // own rows -> first query number
+    __shared__ int s_flag;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+#ifdef WOL_PHASE_STAMPS
+    unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+    // tiles are dealt without divisions: with >= 8 frames in flight each XCD (blocks b, b+8, ...
+    // share one) walks its own frames so a frame's arrays stay in that XCD's L2 (speed only)
+    const bool aff = a.xcd_affine != 0;
+    const int fstep = aff ? 8 : 1;
+    const int tstep = aff ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    int f = aff ? (int)(blockIdx.x & 7) : 0;
+    int tile = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
-    for (int it = 0;; ++it) {
-        int f, tile;
-        if (!wol_fast_tile_of(a, it, &f, &tile)) break;
+    for (;; tile += tstep) {
+        while (tile >= a.tiles_per_frame) { tile -= a.tiles_per_frame; f += fstep; }
+        if (f >= a.F) break;
         const FrameGrid& g = a.grids[f];
         if (tile >= g.ntiles || g.maxshell < 0 || !g.fast_ok) continue;  // uniform over the block
         const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
-        const int tx = tile % g.ntx, ty = (tile / g.ntx) % g.nty, cz = tile / (g.ntx * g.nty);
+        // tile -> (tx, ty, cz) through float reciprocals (exact for these small operands)
+        const int ntxy = g.ntx * g.nty;
+        const int cz = (int)(((float)tile + 0.5f) / (float)ntxy);
+        const int trem = tile - cz * ntxy;
+        const int ty = (int)(((float)trem + 0.5f) / (float)g.ntx);
+        const int tx = trem - ty * g.ntx;
         const int x0 = tx * g.sx, sxe = min(g.sx, nx - x0);
         const int y0 = ty * g.ry, re = min(g.ry, ny - y0);
         const int rpl = re + 2;           // staged rows per z layer
-        const int nrows = 3 * rpl, ncr = sxe + 2, ntab = nrows * ncr;
-        const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+        const int nrows = 3 * rpl, ncr = sxe + 2;
+        const float4* __restrict__ sp32 = a.sorted32 + (int64_t)f * a.n;
         const int* __restrict__ cs = a.cell_start + g.cell_base;
         const int64_t frame_off = (int64_t)f * a.n;
+        const float fx = (float)(g.cw[0] * (double)g.scale), fy = (float)(g.cw[1] * (double)g.scale);
+        const float fz = (float)(g.cw[2] * (double)g.scale);
 
-        __syncthreads();  // the previous tile is done with the LDS tables
-        // ---- phase 1: population of every staged cell (kept in registers for phase 3) ----
-        int c_src[4], c_cnt[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int i = tid + m * WOL_BLOCK;
-            c_src[m] = 0; c_cnt[m] = 0;
-            if (i < ntab) {
-                const int r = i / ncr, k = i - r * ncr;
-                const int zi = r / rpl, yi = r - zi * rpl;
-                const int gz = wol_wrap_cell(cz + zi - 1, nz), gy = wol_wrap_cell(y0 + yi - 1, ny);
-                const int gx = wol_wrap_cell(x0 + k - 1, nx);
-                const int cell = (gz * ny + gy) * nx + gx;
-                c_src[m] = cs[cell];
-                c_cnt[m] = cs[cell + 1] - c_src[m];
-                cellpos[r * WOL_CP + k] = c_cnt[m];
+        if (tid == 0) s_flag = 0;  // (every thread copied the previous tile's flag before its last barrier)
+        __syncthreads();           // the previous tile is done with the LDS tables
+        WOL_STAMP(0);
+        // ---- phase 1: 16 lanes per staged row, one per cell (k = 0 left halo cell, 1..sxe the tile's
+        //      own, sxe+1 right halo; halos wrap): population and first slot, one L2 round trip for
+        //      the whole table; the row length (cells padded to even) by a 16-lane butterfly ----
+        {
+            const int k = tid & 15;
+            for (int r = tid >> 4; r < ((nrows + 1) & ~1); r += WOL_FAST_BLOCK >> 4) {
+                int cnt = 0, src = 0;
+                if (r < nrows && k < ncr) {
+                    const int zi = (r >= rpl) + (r >= 2 * rpl), yi = r - zi * rpl;
+                    const int gz = wol_wrap_cell(cz + zi - 1, nz), gy = wol_wrap_cell(y0 + yi - 1, ny);
+                    const int c = (gz * ny + gy) * nx + wol_wrap_cell(x0 + k - 1, nx);
+#ifdef WOL_EXP_NO_CS_LOAD   // ablation build: timing only, results are wrong
+                    src = c * 2; cnt = 2 + (c & 1);
+#else
+                    src = cs[c];
+                    cnt = cs[c + 1] - src;
+#endif
+                    cellsrc[r * WOL_CP + k] = src;
+                    cellcnt[r * WOL_CP + k] = (unsigned char)min(cnt, 255);
+                    if (cnt > WOL_FAST_MAXCELL) s_flag = 1;
+                }
+                int len = (cnt + 1) & ~1;
+                len += __shfl_xor(len, 1, 64); len += __shfl_xor(len, 2, 64);
+                len += __shfl_xor(len, 4, 64); len += __shfl_xor(len, 8, 64);
+                if (k == 0 && r < nrows) rowlen[r] = len;
             }
         }
         __syncthreads();
-        // ---- phase 2: exclusive scan, row-major over (row, cell) ----
-        if (tid < WOL_FAST_MAXROWS) {
-            int s = 0;
-            if (tid < nrows)
-                for (int k = 0; k < ncr; ++k) s += cellpos[tid * WOL_CP + k];
-            int inc = s;  // inclusive scan across the 64 lanes of wave 0
+        WOL_STAMP(1);
+        // ---- phase 2: row bases by a wave scan, then every row lays out its cells (even starts) ----
+        if (wave == 0) {
+            int run = 0;  // nrows <= 96: two rounds of 64
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                const int len = (r < nrows) ? rowlen[r] : 0;
+                int inc = len;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += v;
+                }
+                if (r < nrows) rowlen[r] = run + inc - len;  // exclusive
+                run += __shfl(inc, 63, 64);
             }
-            rowsum[tid] = inc - s;
+            if (lane == 0) {
+                if (run > 2 * WOL_FAST_CAPP) s_flag = 1;
+                qrow[WOL_FAST_MAXRY + 1] = run;  // total entries incl. padding
+            }
         }
         __syncthreads();
         if (tid < nrows) {
-            int run = rowsum[tid];
+            int pos = rowlen[tid];
             for (int k = 0; k < ncr; ++k) {
-                const int c = cellpos[tid * WOL_CP + k];
-                cellpos[tid * WOL_CP + k] = run;
-                run += c;
+                cellpos[tid * WOL_CP + k] = (unsigned short)pos;
+                pos += ((int)cellcnt[tid * WOL_CP + k] + 1) & ~1;
             }
-            cellpos[tid * WOL_CP + ncr] = run;
+            cellpos[tid * WOL_CP + ncr] = (unsigned short)pos;
         }
-        __syncthreads();
-        const int total = cellpos[(nrows - 1) * WOL_CP + ncr];
-        const bool overflow = total > WOL_FAST_CAP;
-        // ---- phase 3: stage the halo'd tile as scaled fp32, images shifted into the local frame ----
-        if (!overflow) {
-            const double fx = g.cw[0] * (double)g.scale, fy = g.cw[1] * (double)g.scale, fz = g.cw[2] * (double)g.scale;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int i = tid + m * WOL_BLOCK;
-                if (i >= ntab) break;
-                const int r = i / ncr, k = i - r * ncr;
-                const int zi = r / rpl, yi = r - zi * rpl;
-                const int uz = cz + zi - 1, uy = y0 + yi - 1, ux = x0 + k - 1;  // unwrapped cell coordinates
-                // offsets (in cells) that move a wrapped coordinate into the tile frame
-                const double ox = (double)(ux - wol_wrap_cell(ux, nx) - x0);
-                const double oy = (double)(uy - wol_wrap_cell(uy, ny) - y0);
-                const double oz = (double)(uz - wol_wrap_cell(uz, nz) - cz);
-                const int src = c_src[m], cnt = c_cnt[m];
-                const int dst = cellpos[r * WOL_CP + k];
-                for (int e0 = 0; e0 < cnt; e0 += 4) {
-                    double4 v[4];
-#pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4)  // issue the loads together, then convert
-                        if (e0 + u4 < cnt) v[u4] = sp[src + e0 + u4];
-#pragma unroll
-                    for (int u4 = 0; u4 < 4; ++u4) {
-                        if (e0 + u4 < cnt) {
-                            double u;
-                            float4 o;
-                            u = v[u4].x * g.box.ib[0]; u -= floor(u); o.x = (float)((u * (double)nx + ox) * fx);
-                            u = v[u4].y * g.box.ib[1]; u -= floor(u); o.y = (float)((u * (double)ny + oy) * fy);
-                            u = v[u4].z * g.box.ib[2]; u -= floor(u); o.z = (float)((u * (double)nz + oz) * fz);
-                            o.w = __int_as_float(src + e0 + u4);
-                            ent[dst + e0 + u4] = o;
-                            ent_k[dst + e0 + u4] = (unsigned char)k;
-                        }
-                    }
-                }
-            }
-        }
-        // ---- phase 4: the tile's own waters: rows 1..re of the middle layer, cells 1..sxe ----
-        if (tid < 64) {
+        // own rows: running number of the tile's waters (queries)
+        if (wave == 1) {
             int c = 0;
-            if (tid < re) {
-                const int r = rpl + tid + 1;
-                c = cellpos[r * WOL_CP + sxe + 1] - cellpos[r * WOL_CP + 1];
+            if (lane < re) {
+                const int r = rpl + lane + 1;
+                for (int k = 1; k <= sxe; ++k) c += cellcnt[r * WOL_CP + k];
             }
             int inc = c;
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {
                 const int v = __shfl_up(inc, off, 64);
-                if (tid >= off) inc += v;
+                if (lane >= off) inc += v;
             }
-            if (tid <= WOL_FAST_MAXRY) qstart[tid + 1] = inc;
-            if (tid == 0) qstart[0] = 0;
+            if (lane < WOL_FAST_MAXRY) qrow[lane + 1] = inc;
+            if (lane == 0) qrow[0] = 0;
         }
         __syncthreads();
-        const int nq = qstart[re];
+        const bool overflow = s_flag != 0;
+        const int total_e = qrow[WOL_FAST_MAXRY + 1];
+        const int dummy_p = (total_e >> 1) + WOL_FAST_PADP - 2;  // behind the read head-room
+        WOL_STAMP(2);
+        // ---- phase 3: stage.  16 lanes per row, one per cell: two waters at a time become one pair
+        //      record; an odd cell is completed (and the head-room filled) with far-away dummies ----
+        if (!overflow) {
+            const int k = tid & 15;
+            for (int r = tid >> 4; r < nrows; r += WOL_FAST_BLOCK >> 4) {
+                if (k >= ncr) continue;
+                const int zi = (r >= rpl) + (r >= 2 * rpl), yi = r - zi * rpl;
+                const int src = cellsrc[r * WOL_CP + k], cnt = cellcnt[r * WOL_CP + k];
+                const int pos = cellpos[r * WOL_CP + k];
+                // x: wrapped coordinate from the box origin -> tile frame (halo images shifted)
+                float offx = -(float)x0 * fx;
+                if (k == 0 && x0 == 0) offx -= (float)nx * fx;
+                if (k == ncr - 1 && x0 + sxe == nx) offx += (float)nx * fx;
+                const float offy = (float)(yi - 1) * fy, offz = (float)(zi - 1) * fz;
+                for (int e0 = 0; e0 < cnt; e0 += 6) {
+                    float4 v[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)  // up to six waters of the cell in flight together
+#ifdef WOL_EXP_NO_STAGE_LOAD   // ablation build: timing only, results are wrong
+                        if (e0 + u < cnt) { v[u].x = (float)(src + u); v[u].y = (float)(k + u); v[u].z = (float)r; v[u].w = 0.f; }
+#else
+                        if (e0 + u < cnt) v[u] = sp32[src + e0 + u];
+#endif
+#pragma unroll
+                    for (int u = 0; u < 6; u += 2) {
+                        const int e = e0 + u;
+                        if (e < cnt) {
+                            const bool two = e + 1 < cnt;
+                            float4 ra, rb;
+                            ra.x = v[u].x + offx; ra.z = v[u].y + offy; rb.x = v[u].z + offz;
+                            ra.y = two ? v[u + 1].x + offx : 1.0e7f;
+                            ra.w = two ? v[u + 1].y + offy : 1.0e7f;
+                            rb.y = two ? v[u + 1].z + offz : 1.0e7f;
+                            rb.z = __int_as_float(pos + e); rb.w = __int_as_float(pos + e + 1);
+                            const int p = (pos + e) >> 1;
+                            rec[2 * p] = ra; rec[2 * p + 1] = rb;
+                            slot[pos + e] = src + e;
+                            slot[pos + e + 1] = two ? src + e + 1 : src + e;
+                        }
+                    }
+                }
+            }
+            if (tid < WOL_FAST_PADP) {  // head-room pairs (incl. the dummy pair): nothing near
+                const int p = (total_e >> 1) + tid;
+                float4 far;
+                far.x = far.y = far.z = far.w = 1.0e7f;
+                rec[2 * p] = far;
+                far.z = far.w = __int_as_float(0);
+                rec[2 * p + 1] = far;
+            }
+        }
+        __syncthreads();
+        const int nq = qrow[re];
+        WOL_STAMP(3);
 
-        for (int qb = 0; qb < nq; qb += WOL_BLOCK) {
-            const int qi = qb + tid;
+        for (int qb = wave * 64; qb < nq; qb += WOL_FAST_BLOCK) {
+            const int qi = qb + lane;
             if (qi >= nq) continue;
             int ly = 0;
-            while (ly + 1 < re && qstart[ly + 1] <= qi) ++ly;
+            while (ly + 1 < re && qrow[ly + 1] <= qi) ++ly;
             const int rq = rpl + ly + 1;
-            const int self_e = cellpos[rq * WOL_CP + 1] + (qi - qstart[ly]);
-            // slot of this water in the sorted array: the tile's cells of a row are contiguous there
-            const int self_slot = cs[(cz * ny + (y0 + ly)) * nx + x0] + (qi - qstart[ly]);
+            // own cell and entry: walk the row's cells
+            int lx = 0, left = qi - qrow[ly];
+            while (lx + 1 < sxe && left >= (int)cellcnt[rq * WOL_CP + lx + 1]) { left -= cellcnt[rq * WOL_CP + lx + 1]; ++lx; }
+            const int self_slot = cellsrc[rq * WOL_CP + lx + 1] + left;
             int4 prop;
             prop.x = prop.y = prop.z = prop.w = 0;
             int kd3 = -1;
             if (!overflow) {
+                const int self_e = cellpos[rq * WOL_CP + lx + 1] + left;
+                const float4 ma = rec[2 * (self_e >> 1)], mb = rec[2 * (self_e >> 1) + 1];
+                const bool odd = self_e & 1;
+                const float mx = odd ? ma.y : ma.x, my = odd ? ma.w : ma.z, mz = odd ? mb.y : mb.x;
+                const wol_f2 xi = {mx, mx}, yi = {my, my}, zi = {mz, mz};
+                const unsigned tmaxbits = __float_as_uint(g.tmax);
                 unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
-                const float4 me = ent[self_e];
-                const int lx = (int)ent_k[self_e] - 1;  // 0-based cell of the water inside the tile
 #pragma unroll
                 for (int dzi = 0; dzi < 3; ++dzi) {
 #pragma unroll
                     for (int dyi = 0; dyi < 3; ++dyi) {
                         const int r = dzi * rpl + ly + dyi;
-                        const int b = cellpos[r * WOL_CP + lx], e = cellpos[r * WOL_CP + lx + 3];
+                        const int pb = cellpos[r * WOL_CP + lx] >> 1, pe = cellpos[r * WOL_CP + lx + 3] >> 1;
                         if (dzi == 1 && dyi == 1)
-                            wol_fast_span<true>(ent, b, e, me.x, me.y, me.z, self_e, g.tmax, k0, k1, k2, k3, k4);
+                            wol_fast_span<true>(reinterpret_cast<const char*>(rec), pb, pe - pb, dummy_p * 32, xi, yi, zi, (unsigned)self_e, tmaxbits, k0, k1, k2, k3, k4);
                         else
-                            wol_fast_span<false>(ent, b, e, me.x, me.y, me.z, self_e, g.tmax, k0, k1, k2, k3, k4);
+                            wol_fast_span<false>(reinterpret_cast<const char*>(rec), pb, pe - pb, dummy_p * 32, xi, yi, zi, (unsigned)self_e, tmaxbits, k0, k1, k2, k3, k4);
                     }
                 }
                 // the proposal stands only if it is separated from the 5th candidate by more than the
                 // fp32 error and is not saturated
-                const unsigned d3 = k3 >> 11, d4 = k4 >> 11;
-                const unsigned sat = (1u << 21) - 1u - (unsigned)g.eps_units;
+                const unsigned d3 = k3 >> WOL_ID_BITS, d4 = k4 >> WOL_ID_BITS;
+                const unsigned sat = (1u << (32 - WOL_ID_BITS)) - 1u - (unsigned)g.eps_units;
                 if (k3 != 0xFFFFFFFFu && d3 < sat && d4 - d3 > 2u * (unsigned)g.eps_units) {
-                    prop.x = __float_as_int(ent[k0 & 0x7FFu].w); prop.y = __float_as_int(ent[k1 & 0x7FFu].w);
-                    prop.z = __float_as_int(ent[k2 & 0x7FFu].w); prop.w = __float_as_int(ent[k3 & 0x7FFu].w);
+                    const unsigned m = (1u << WOL_ID_BITS) - 1u;
+                    prop.x = slot[k0 & m]; prop.y = slot[k1 & m]; prop.z = slot[k2 & m]; prop.w = slot[k3 & m];
                     kd3 = (int)d3;
                 }
             }
+#ifdef WOL_EXP_NO_STORE        // ablation build: timing only
+            if (kd3 == 123456789) a.prop_key[frame_off + self_slot] = prop.x;
+#else
             a.prop[frame_off + self_slot] = prop;
             a.prop_key[frame_off + self_slot] = kd3;
+#endif
         }
+        WOL_STAMP(4);
     }
 }
 
@@ -337,10 +439,14 @@ k_finish_fast(FastArgs a) {
     if (lds_qh) wol_hist_zero(lds_qh, a.out.qbins);
     if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
     __syncthreads();
-    const int64_t total = (int64_t)a.F * a.n;
-    for (int64_t w = (int64_t)blockIdx.x * WOL_BLOCK + threadIdx.x; w < total; w += (int64_t)gridDim.x * WOL_BLOCK) {
-        const int f = (int)(w / a.n);
-        const int s = (int)(w - (int64_t)f * a.n);
+    // frames <-> XCDs as in the proposal kernel, so a frame's sorted array is read through one L2
+    const bool aff = a.xcd_affine != 0;
+    const int fstep = aff ? 8 : 1;
+    const int kb = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int KB = aff ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    for (int f = aff ? (int)(blockIdx.x & 7) : 0; f < a.F; f += fstep)
+    for (int s = kb * WOL_BLOCK + threadIdx.x; s < a.n; s += KB * WOL_BLOCK) {
+        const int64_t w = (int64_t)f * a.n + s;
         const FrameGrid& g = a.grids[f];
         if (g.maxshell < 0) continue;  // all-pairs frame
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
@@ -405,7 +511,29 @@ k_finish_fast(FastArgs a) {
     if (lds_dh) wol_hist_flush(lds_dh, a.out.dbins, a.out.dhist);
 }
 
-// exact search for the waters the filter could not certify
+// ---------------------------------------------------------------------------------------------
+// kernel 3: exact search for the waters the filter could not certify -- ONE WAVE PER WATER.
+// The cells of each shell are dealt to the 64 lanes (a lane-serial walk is a chain of dependent
+// L2 round trips); every lane ranks its cells' candidates with the exact arithmetic into its own
+// top-4, a butterfly of sorted-list merges gives all lanes the wave-wide top-4, and the shell loop
+// ends under the same guarantee as wol_search_exact_one.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wol_top4_wave_merge(Top4& t) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double od0 = __shfl_xor(t.d0, off, 64), od1 = __shfl_xor(t.d1, off, 64);
+        const double od2 = __shfl_xor(t.d2, off, 64), od3 = __shfl_xor(t.d3, off, 64);
+        const int oj0 = __shfl_xor(t.j0, off, 64), oj1 = __shfl_xor(t.j1, off, 64);
+        const int oj2 = __shfl_xor(t.j2, off, 64), oj3 = __shfl_xor(t.j3, off, 64);
+        const int os0 = __shfl_xor(t.s0, off, 64), os1 = __shfl_xor(t.s1, off, 64);
+        const int os2 = __shfl_xor(t.s2, off, 64), os3 = __shfl_xor(t.s3, off, 64);
+        top4_insert(t, od0, oj0, os0);  // the two lists hold disjoint candidates at every stage
+        top4_insert(t, od1, oj1, os1);
+        top4_insert(t, od2, oj2, os2);
+        top4_insert(t, od3, oj3, os3);
+    }
+}
+
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_list,
                     const int* __restrict__ slow_count) {
@@ -416,7 +544,10 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
     if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
     __syncthreads();
     const int count = *slow_count;
-    for (int i = blockIdx.x * WOL_BLOCK + threadIdx.x; i < count; i += gridDim.x * WOL_BLOCK) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * WOL_BLOCK + threadIdx.x) >> 6;
+    const int nwaves = (gridDim.x * WOL_BLOCK) >> 6;
+    for (int i = wave; i < count; i += nwaves) {
         const unsigned long long e = slow_list[i];
         const int f = (int)(e >> 32), s = (int)(e & 0xFFFFFFFFu);
         const FrameGrid& g = a.grids[f];
@@ -424,13 +555,62 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
         const int* __restrict__ cs = a.cell_start + g.cell_base;
         const double4 v = sp[s];
         const double c[3] = {v.x, v.y, v.z};
-        Top4 t;
-        wol_search_exact_one(c, g, sp, cs, a.lowsq, a.highsq, a.high, t);
-        const double4 n0 = sp[t.s0], n1 = sp[t.s1], n2 = sp[t.s2], n3 = sp[t.s3];
-        const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
-        const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
-        wol_finish_water(c, t, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + (int)__double_as_longlong(v.w),
-                         lds_qh, lds_dh);
+        double fr[3];
+        int cc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cc[k] = wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr[k]);
+        Top4 mine;   // this lane's candidates, accumulated over the shells
+        top4_init(mine);
+        Top4 all;    // wave-wide merge, identical in every lane
+        top4_init(all);
+        for (int shell = 0; shell <= g.maxshell; ++shell) {
+            // shells 0 and 1 together are the 27-cell cube: deal them in one go
+            if (shell == 0 && g.maxshell >= 1) continue;
+            const int w = 2 * shell + 1;
+            const float inv_w = 1.0f / (float)w;
+            const int ncube = w * w * w;
+            for (int idx = lane; idx < ncube; idx += 64) {
+                const int iz = (int)(((float)idx + 0.5f) * inv_w * inv_w);
+                const int rem = idx - iz * w * w;
+                const int iy = (int)(((float)rem + 0.5f) * inv_w);
+                const int ix = rem - iy * w;
+                const int dx = ix - shell, dy = iy - shell, dz = iz - shell;
+                const bool on_shell = (abs(dx) == shell) || (abs(dy) == shell) || (abs(dz) == shell);
+                if (!(on_shell || shell == 1)) continue;  // interior cells belong to earlier shells
+                if (dx < -g.lo[0] || dx > g.hi[0] || dy < -g.lo[1] || dy > g.hi[1] || dz < -g.lo[2] || dz > g.hi[2])
+                    continue;                             // clipped: small periodic grids visit a cell once
+                const int cx = wol_wrap_cell(cc[0] + dx, g.nc[0]);
+                const int cy = wol_wrap_cell(cc[1] + dy, g.nc[1]);
+                const int cz = wol_wrap_cell(cc[2] + dz, g.nc[2]);
+                const int cell = (cz * g.nc[1] + cy) * g.nc[0] + cx;
+                const int b = cs[cell], en = cs[cell + 1];
+                for (int j = b; j < en; ++j) {
+                    const double4 p = sp[j];
+                    double dist;
+                    bool in_mask;
+                    if (wol_eval_pair(c, p.x, p.y, p.z, g.box, a.lowsq, a.highsq, mine.bound2, &dist, &in_mask))
+                        top4_insert(mine, dist, (int)__double_as_longlong(p.w), j);
+                }
+            }
+            all = mine;
+            wol_top4_wave_merge(all);
+            double rg = __builtin_huge_val();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const bool whole = (shell >= g.lo[k]) && (shell >= g.hi[k]) && (g.lo[k] + g.hi[k] + 1 >= g.nc[k]);
+                if (!whole) rg = fmin(rg, (double)shell * g.cw[k] + fmin(fr[k], 1.0 - fr[k]) * g.cw[k]);
+            }
+            rg -= 1e-6;
+            if (rg >= a.high) break;
+            if (all.n == 4 && all.d3 <= rg) break;
+        }
+        if (lane == 0) {
+            const double4 n0 = sp[all.s0], n1 = sp[all.s1], n2 = sp[all.s2], n3 = sp[all.s3];
+            const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
+            const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
+            wol_finish_water(c, all, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + (int)__double_as_longlong(v.w),
+                             lds_qh, lds_dh);
+        }
     }
     __syncthreads();
     if (lds_qh) wol_hist_flush(lds_qh, a.out.qbins, a.out.qhist);
