@@ -181,3 +181,81 @@ def test_traj_device_resident_matches_host():
     b = engine.tet_order_traj(x32.astype(np.float64), boxes, want_q=True)
     assert np.array_equal(a.qhist, b.qhist) and np.array_equal(a.dhist, b.dhist)
     assert np.array_equal(a.mean, b.mean) and np.array_equal(a.q, b.q.astype(np.float32))
+
+
+# ---- getCosAngs / getLSI ------------------------------------------------
+@pytest.mark.parametrize("name", ["gas512", "ice512", "ortho2000_unwrapped", "sparse_clusters", "subpop_rows",
+                                  "subpop_points", "tiny_box", "nonperiodic_z"])
+def test_cos_angs_and_lsi_golden(wp, name):
+    g = golden(name)
+    sub, pos, box, _, _ = case_inputs(g)
+    ca, cn = wp.getCosAngs(sub, pos, box)
+    assert ca.shape == g["cos_ang"].shape and np.array_equal(cn, g["cos_num"])
+    np.testing.assert_allclose(ca, g["cos_ang"], rtol=0, atol=ANG_TOL)
+    h, _ = np.histogram(ca, bins=500, range=[0.0, 180.0])
+    assert np.array_equal(h, g["ang_hist"])
+    li, ln = wp.getLSI(sub, pos, box)
+    assert li.shape == g["lsi"].shape and np.array_equal(ln, g["lsi_num"])
+    np.testing.assert_allclose(li, g["lsi"], rtol=0, atol=1e-13)
+
+
+def test_cos_angs_and_lsi_vs_oracle(wp, oracle):
+    from waterorderlib_amd import synth
+    xyz, boxes = synth.water_frames(4000, 1, seed=91)
+    pos, box = xyz[0], boxes[0] * np.array([1.0, 1.0, 1.0])
+    for lo, hi in ((0.0, 3.413), (2.6, 3.8)):
+        ca, cn = wp.getCosAngs(pos, pos, box, lo, hi)
+        ra, rn = oracle.getCosAngs(pos, pos, box, lo, hi)
+        assert np.array_equal(cn, rn) and ca.shape == ra.shape
+        np.testing.assert_allclose(ca, ra, rtol=0, atol=ANG_TOL)
+    li, ln = wp.getLSI(pos, pos, box)
+    ri, rn = oracle.getLSI(pos, pos, box)
+    assert np.array_equal(ln, rn) and li.shape == ri.shape
+    np.testing.assert_allclose(li, ri, rtol=0, atol=1e-13)
+    sub = pos[::7] + 0.01
+    li, ln = wp.getLSI(sub, pos, box, 0.0, 3.5)
+    ri, rn = oracle.getLSI(sub, pos, box, 0.0, 3.5)
+    assert np.array_equal(ln, rn)
+    np.testing.assert_allclose(li, ri, rtol=0, atol=1e-13)
+    # tetrahedralMetrics on top (host numpy, as in the reference)
+    ca, _ = wp.getCosAngs(pos, pos, box)
+    dist, bins, frac, avg, var, ent = wp.tetrahedralMetrics(ca)
+    assert dist.sum() == len(ca) and 0.0 < frac < 1.0 and ent > 0.0
+    # empty shells
+    ca, cn = wp.getCosAngs(pos[:50], pos, box, 0.0, 0.5)
+    assert len(ca) == 0 and np.all(cn == 0)
+
+
+@pytest.mark.filterwarnings("ignore:Mean of empty slice", "ignore:invalid value encountered")
+def test_drivers(oracle, tmp_path, monkeypatch):
+    """tetOrderCalc / threeBodyCalc / lsiCalc over an array-backed TrajObject against the oracle"""
+    from waterorderlib_amd import orderParam_lib as opl
+    from waterorderlib_amd import synth
+    from waterorderlib_amd.TrajObject import TrajObject
+    monkeypatch.chdir(tmp_path)
+    xyz, boxes = synth.water_frames(1500, 5, seed=95, len_wat=3)
+    obj = TrajObject(xyz, boxes, lenWat=3)
+    watInds, watH, lenWat = obj.getWatInds()
+    assert lenWat == 3 and len(watInds) == 1500 and len(watH) == 3000
+    rng = np.random.default_rng(0)
+    subInds = [[watInds[rng.choice(1500, 200, replace=False)]] for _ in range(5)]
+    avgQ, varQ = opl.tetOrderCalc(obj, subInds=subInds, nPops=1, rng=np.random.default_rng(1))
+    series_avg, series_var, hists = opl.tetOrderCalc.last_series
+    O = np.ascontiguousarray(xyz[:, 0::3])
+    for t in range(5):
+        q = oracle.getOrderParamq(O[t], O[t], boxes[t])
+        assert abs(series_avg[0][t] - np.mean(q)) < 1e-13 and abs(series_var[0][t] - np.var(q)) < 1e-13
+        qs = oracle.getOrderParamq(xyz[t][subInds[t][0]], O[t], boxes[t])
+        assert abs(series_avg[1][t] - np.mean(qs)) < 1e-12
+    assert abs(avgQ[0][0] - np.mean(series_avg[0])) < 1e-15 and avgQ[0][1] > 0.0
+    # (with fewer than 20 frames the reference's 20-block CI is NaN; the mirror keeps that behaviour)
+    tab = np.loadtxt("qDistribution_0.txt")
+    assert tab.shape == (500, 2) and tab[:, 1].sum() == hists[0].sum()
+    pTet, avgCos, varCos, ent, nW = opl.threeBodyCalc(obj, rng=np.random.default_rng(2))
+    ang = np.concatenate([oracle.getCosAngs(O[t], O[t], boxes[t])[0] for t in range(5)])
+    np.testing.assert_allclose(np.sort(opl.threeBodyCalc.last_angles[0]), np.sort(ang), rtol=0, atol=ANG_TOL)
+    assert nW[0][0] == 1500 and 0.0 < pTet[0][0] < 1.0 and np.loadtxt("3bDistribution_0.txt").shape == (500, 2)
+    avgL, varL = opl.lsiCalc(obj, rng=np.random.default_rng(3))
+    l0 = [oracle.getLSI(O[t], O[t], boxes[t])[0] for t in range(5)]
+    assert abs(avgL[0][0] - np.mean([np.mean(x) for x in l0])) < 1e-13
+    assert np.loadtxt("lsiDistribution_0.txt").shape == (500, 2)

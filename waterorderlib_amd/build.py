@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwol.so")
-SOURCES = ["wol_api.hip", "wol_kernels.hip", "wol_search_fast.hip", "wol_device.h"]
+SOURCES = ["wol_api.hip", "wol_kernels.hip", "wol_search_fast.hip", "wol_shell.hip", "wol_device.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 

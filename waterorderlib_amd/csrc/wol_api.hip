@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared wol_api.hip -o libwol.so
 #include "wol_kernels.hip"
 #include "wol_search_fast.hip"
+#include "wol_shell.hip"
 
 #include <cmath>
 #include <cstdarg>
@@ -385,6 +386,51 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         if (c->time_kernels) WOL_TRY(end_timing(c, ev));
     }
     HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+// Single-frame set-up shared by wol_cos_angs / wol_lsi_frame: upload, bin, cell-sort; the grid is
+// built for the given reach so walking cells [-lo, hi]^3 sees every neighbour inside it.
+int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+                double reach, ShellArgs* sa) {
+    if (c->grid_copy_pending) {
+        HIP_TRY(hipEventSynchronize(c->grid_ev));
+        c->grid_copy_pending = false;
+    }
+    WOL_TRY(c->grids_host.ensure(sizeof(FrameGrid)));
+    FrameGrid* gh = c->grids_host.as<FrameGrid>();
+    const bool ok = make_grid(box, n, std::fmax(reach * 0.5, 2.5), reach, gh);
+    if (!ok) { gh->ncell = 1; for (int k = 0; k < 3; ++k) gh->nc[k] = 1; }
+    gh->cell_base = 0;
+    const size_t pe = 3 * (size_t)n, se = sub ? 3 * (size_t)ns : 0;
+    WOL_TRY(c->in_stage.ensure(sizeof(double) * (pe + se)));
+    WOL_TRY(c->grids.ensure(sizeof(FrameGrid)));
+    WOL_TRY(c->cells.ensure(sizeof(int) * (size_t)(gh->ncell + 1)));
+    WOL_TRY(c->sorted.ensure(sizeof(double4) * (size_t)n));
+    WOL_TRY(c->cellid.ensure(sizeof(int) * (size_t)n));
+    WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)n));
+    HIP_TRY(hipMemcpyAsync(c->in_stage.p, pos, sizeof(double) * pe, hipMemcpyHostToDevice, c->stream));
+    if (sub) HIP_TRY(hipMemcpyAsync(c->in_stage.as<double>() + pe, sub, sizeof(double) * se, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->grids.p, gh, sizeof(FrameGrid), hipMemcpyHostToDevice, c->stream));
+    if (!c->grid_ev) HIP_TRY(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
+    c->grid_copy_pending = true;
+    HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)(gh->ncell + 1), c->stream));
+    FramesView<double> fv{c->in_stage.as<double>(), 3, 0, n};
+    const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, 1);
+    hipLaunchKernelGGL(k_bin_count<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                       c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
+    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
+    hipLaunchKernelGGL(k_scatter<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                       c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>(),
+                       (float4*)nullptr);
+    sa->grid = c->grids.as<FrameGrid>();
+    sa->sorted = c->sorted.as<double4>();
+    sa->cell_start = c->cells.as<int>();
+    sa->n = n;
+    sa->sub = sub ? c->in_stage.as<double>() + pe : nullptr;
+    sa->ns = sub ? ns : n;
+    sa->use_cells = ok ? 1 : 0;
     return WOL_OK;
 }
 
@@ -777,14 +823,89 @@ int wol_q_frame(wol_ctx* c, const double* pos, int64_t pos_stride, int n, const 
 
 int wol_cos_angs(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
                  double lowcut, double highcut, double* ang, double* num_angs, int64_t* total) {
-    (void)c; (void)pos; (void)n; (void)sub; (void)ns; (void)box; (void)lowcut; (void)highcut; (void)ang; (void)num_angs; (void)total;
-    return fail(WOL_ERR_INVALID, "wol_cos_angs: not implemented yet");
+    WOL_TRY(check_ctx(c));
+    if (!pos || !box || !total || n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "cos_angs: bad argument");
+    if (!sub) ns = n;
+    *total = 0;
+    if (ns == 0) return WOL_OK;
+    if (n == 0) {
+        if (num_angs) for (int i = 0; i < ns; ++i) num_angs[i] = 0.0;
+        return WOL_OK;
+    }
+    ShellArgs sa;
+    WOL_TRY(shell_setup(c, pos, n, sub, ns, box, highcut, &sa));
+    sa.lowsq = lowcut * lowcut;
+    sa.highsq = highcut * highcut;
+    // layout of `small`: count[ns] ints | off_nbr[ns] | off_ang[ns] | totals[2] (long long)
+    const size_t o_off = ((sizeof(int) * (size_t)ns + 15) / 16) * 16;
+    WOL_TRY(c->small.ensure(o_off + sizeof(long long) * (2 * (size_t)ns + 2)));
+    int* d_count = c->small.as<int>();
+    long long* d_offn = reinterpret_cast<long long*>(c->small.as<char>() + o_off);
+    long long* d_offa = d_offn + ns;
+    long long* d_tot = d_offa + ns;
+    const dim3 grid((ns + WOL_BLOCK - 1) / WOL_BLOCK);
+    hipLaunchKernelGGL(k_shell_count, grid, dim3(WOL_BLOCK), 0, c->stream, sa, d_count);
+    hipLaunchKernelGGL(k_shell_offsets, dim3(1), dim3(1024), 0, c->stream, d_count, ns, d_offn, d_offa, d_tot);
+    long long tot[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int> hcount;
+    if (num_angs) {
+        hcount.resize((size_t)ns);
+        HIP_TRY(hipMemcpyAsync(hcount.data(), d_count, sizeof(int) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (num_angs) for (int i = 0; i < ns; ++i) num_angs[i] = (double)hcount[(size_t)i];
+    *total = (int64_t)tot[1];
+    if (!ang || tot[1] == 0) return WOL_OK;
+    WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)std::max<long long>(tot[0], 1)));
+    WOL_TRY(c->out_stage.ensure(sizeof(double) * (size_t)tot[1]));
+    hipLaunchKernelGGL(k_cos_angs_fill, grid, dim3(WOL_BLOCK), 0, c->stream, sa, d_offn, d_offa,
+                       c->slow_list.as<unsigned long long>(), c->out_stage.as<double>());
+    HIP_TRY(hipMemcpyAsync(ang, c->out_stage.p, sizeof(double) * (size_t)tot[1], hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
 }
 
 int wol_lsi_frame(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
                   double lowcut, double highcut, double* lsi_full, double* num_lsi, int64_t* nvalid) {
-    (void)c; (void)pos; (void)n; (void)sub; (void)ns; (void)box; (void)lowcut; (void)highcut; (void)lsi_full; (void)num_lsi; (void)nvalid;
-    return fail(WOL_ERR_INVALID, "wol_lsi_frame: not implemented yet");
+    WOL_TRY(check_ctx(c));
+    if (!pos || !box || !lsi_full || n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "lsi_frame: bad argument");
+    if (!sub) ns = n;
+    if (nvalid) *nvalid = 0;
+    if (ns == 0) return WOL_OK;
+    if (n == 0) {
+        for (int i = 0; i < ns; ++i) { lsi_full[i] = NAN; if (num_lsi) num_lsi[i] = 0.0; }
+        return WOL_OK;
+    }
+    const double high2 = highcut + 3.7;  // water_properties.py:276,281
+    ShellArgs sa;
+    WOL_TRY(shell_setup(c, pos, n, sub, ns, box, high2, &sa));
+    sa.lowsq = lowcut * lowcut;
+    sa.highsq = highcut * highcut;
+    WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)WOL_LSI_CAP * (size_t)ns));
+    WOL_TRY(c->out_stage.ensure(sizeof(double) * 2 * (size_t)ns));
+    WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
+    HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+    double* d_lsi = c->out_stage.as<double>();
+    double* d_num = d_lsi + ns;
+    hipLaunchKernelGGL(k_lsi, dim3((ns + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream, sa,
+                       high2 * high2, c->qbuf.as<double>(), d_lsi, d_num, c->slow_count.as<int>());
+    std::vector<double> hnum((size_t)ns);
+    int over = 0;
+    HIP_TRY(hipMemcpyAsync(lsi_full, d_lsi, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hnum.data(), d_num, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&over, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (over) return fail(WOL_ERR_INVALID, "lsi_frame: a water has more than %d neighbours inside highcut", WOL_LSI_CAP - 2);
+    int64_t nv = 0;
+    for (int i = 0; i < ns; ++i) {
+        if (num_lsi) num_lsi[i] = hnum[(size_t)i];
+        nv += (lsi_full[i] == lsi_full[i]) ? 1 : 0;
+    }
+    if (nvalid) *nvalid = nv;
+    return WOL_OK;
 }
 
 // ---- level 3 ------------------------------------------------------------------------------

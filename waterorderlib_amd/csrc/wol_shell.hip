@@ -1,0 +1,232 @@
+// wol_shell.hip -- shell-neighbour kernels behind wol_cos_angs (water_properties.py:210-250) and
+// wol_lsi_frame (water_properties.py:252-311); included by wol_api.hip.
+//
+// Both need EVERY neighbour inside a cutoff shell (not just the nearest four), in ascending
+// original index (the order of `Pos[nearNeighbs[i]]` in the reference).  One lane per query walks
+// all cells the cutoff can reach (grid built with that reach, so no early exit and no list is
+// missed) or, for boxes with a non-periodic axis, all positions.  Variable-length results use a
+// count pass, a device scan and a fill pass; per-query neighbour lists live in a global scratch
+// segment that the lane sorts in place (shells hold ~4-10 waters).
+#pragma once
+
+struct ShellArgs {
+    const FrameGrid* grid;     // single frame
+    const double4* sorted;     // cell-sorted positions (x, y, z, original index)
+    const int* cell_start;
+    int n;                     // candidates
+    const double* sub;         // queries, row stride 3; null = the candidates themselves (sorted order)
+    int ns;
+    int use_cells;             // 0: all-pairs over `sorted` (any box)
+    double lowsq, highsq;
+};
+
+// calls f(slot, d2, dx, dy, dz) for every candidate whose exact minimum-image d2 can matter
+template <typename F>
+__device__ __forceinline__ void wol_for_each_candidate(const ShellArgs& a, const double c[3], F f) {
+    const FrameGrid& g = *a.grid;
+    const double4* __restrict__ sp = a.sorted;
+    if (!a.use_cells) {
+        for (int j = 0; j < a.n; ++j) {
+            const double4 v = sp[j];
+            const double dx = wol_minimg1(v.x - c[0], g.box.L[0], g.box.ib[0]);
+            const double dy = wol_minimg1(v.y - c[1], g.box.L[1], g.box.ib[1]);
+            const double dz = wol_minimg1(v.z - c[2], g.box.L[2], g.box.ib[2]);
+            f(j, wol_sumsq(dx, dy, dz), dx, dy, dz);
+        }
+        return;
+    }
+    const int* __restrict__ cs = a.cell_start + g.cell_base;
+    int cc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cc[k] = wol_cell_coord(c[k], g.box.ib[k], g.nc[k], nullptr);
+    for (int dz = -g.lo[2]; dz <= g.hi[2]; ++dz) {
+        const int cz = wol_wrap_cell(cc[2] + dz, g.nc[2]);
+        for (int dy = -g.lo[1]; dy <= g.hi[1]; ++dy) {
+            const int cy = wol_wrap_cell(cc[1] + dy, g.nc[1]);
+            for (int dx = -g.lo[0]; dx <= g.hi[0]; ++dx) {
+                const int cx = wol_wrap_cell(cc[0] + dx, g.nc[0]);
+                const int cell = (cz * g.nc[1] + cy) * g.nc[0] + cx;
+                const int b = cs[cell], e = cs[cell + 1];
+                for (int j = b; j < e; ++j) {
+                    const double4 v = sp[j];
+                    const double ex = wol_minimg1(v.x - c[0], g.box.L[0], g.box.ib[0]);
+                    const double ey = wol_minimg1(v.y - c[1], g.box.L[1], g.box.ib[1]);
+                    const double ez = wol_minimg1(v.z - c[2], g.box.L[2], g.box.ib[2]);
+                    f(j, wol_sumsq(ex, ey, ez), ex, ey, ez);
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wol_shell_query(const ShellArgs& a, int q, double c[3], int* out_row) {
+    if (a.sub) {
+        c[0] = a.sub[3 * (int64_t)q]; c[1] = a.sub[3 * (int64_t)q + 1]; c[2] = a.sub[3 * (int64_t)q + 2];
+        *out_row = q;
+    } else {
+        const double4 v = a.sorted[q];
+        c[0] = v.x; c[1] = v.y; c[2] = v.z;
+        *out_row = (int)__double_as_longlong(v.w);
+    }
+}
+
+// ---- pass 1: neighbours in the shell per query (by output row) ------------------------------
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_shell_count(ShellArgs a, int* __restrict__ count) {
+    const int q = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (q >= a.ns) return;
+    double c[3];
+    int row;
+    wol_shell_query(a, q, c, &row);
+    int k = 0;
+    wol_for_each_candidate(a, c, [&](int, double d2, double, double, double) {
+        k += (d2 > a.lowsq && d2 <= a.highsq) ? 1 : 0;
+    });
+    count[row] = k;
+}
+
+// exclusive scans of k and of k(k-1)/2 over the rows (one block; ns is at most a few 1e5)
+__global__ void __launch_bounds__(1024)
+k_shell_offsets(const int* __restrict__ count, int ns, long long* __restrict__ off_nbr,
+                long long* __restrict__ off_ang, long long* __restrict__ totals) {
+    __shared__ long long pa[1024], pb[1024];
+    const int tid = threadIdx.x;
+    const int per = (ns + 1023) / 1024;
+    const int b = min(tid * per, ns), e = min(b + per, ns);
+    long long sa = 0, sb = 0;
+    for (int i = b; i < e; ++i) { const long long k = count[i]; sa += k; sb += k * (k - 1) / 2; }
+    pa[tid] = sa; pb[tid] = sb;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const long long va = tid >= off ? pa[tid - off] : 0, vb = tid >= off ? pb[tid - off] : 0;
+        __syncthreads();
+        pa[tid] += va; pb[tid] += vb;
+        __syncthreads();
+    }
+    long long ra = pa[tid] - sa, rb = pb[tid] - sb;
+    for (int i = b; i < e; ++i) {
+        const long long k = count[i];
+        off_nbr[i] = ra; off_ang[i] = rb;
+        ra += k; rb += k * (k - 1) / 2;
+    }
+    if (tid == 1023) { totals[0] = pa[1023]; totals[1] = pb[1023]; }
+}
+
+// ---- getCosAngs pass 2: list the shell (ascending original index), all pair angles ----------
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_cos_angs_fill(ShellArgs a, const long long* __restrict__ off_nbr, const long long* __restrict__ off_ang,
+                unsigned long long* __restrict__ nbr, double* __restrict__ ang) {
+    const int q = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (q >= a.ns) return;
+    double c[3];
+    int row;
+    wol_shell_query(a, q, c, &row);
+    unsigned long long* __restrict__ lst = nbr + off_nbr[row];
+    int k = 0;
+    wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
+        if (d2 > a.lowsq && d2 <= a.highsq) {
+            const unsigned long long key =
+                ((unsigned long long)(unsigned)__double_as_longlong(a.sorted[slot].w) << 32) | (unsigned)slot;
+            int p = k++;  // insertion sort by original index
+            while (p > 0 && lst[p - 1] > key) { lst[p] = lst[p - 1]; --p; }
+            lst[p] = key;
+        }
+    });
+    const FrameGrid& g = *a.grid;
+    double* __restrict__ out = ang + off_ang[row];
+    long long o = 0;
+    for (int u = 0; u < k; ++u) {
+        const double4 pu = a.sorted[(int)(lst[u] & 0xFFFFFFFFu)];
+        double P1[3];  // tetraCosAng re-images every neighbour about the centre (waterlib.f90:881-883)
+        P1[0] = c[0] + wol_minimg1(pu.x - c[0], g.box.L[0], g.box.ib[0]);
+        P1[1] = c[1] + wol_minimg1(pu.y - c[1], g.box.L[1], g.box.ib[1]);
+        P1[2] = c[2] + wol_minimg1(pu.z - c[2], g.box.L[2], g.box.ib[2]);
+        for (int v = u + 1; v < k; ++v) {
+            const double4 pv = a.sorted[(int)(lst[v] & 0xFFFFFFFFu)];
+            double P2[3];
+            P2[0] = c[0] + wol_minimg1(pv.x - c[0], g.box.L[0], g.box.ib[0]);
+            P2[1] = c[1] + wol_minimg1(pv.y - c[1], g.box.L[1], g.box.ib[1]);
+            P2[2] = c[2] + wol_minimg1(pv.z - c[2], g.box.L[2], g.box.ib[2]);
+            out[o++] = wol_cos_angle3(P1, c, P2);
+        }
+    }
+}
+
+// ---- getLSI --------------------------------------------------------------------------------
+// numpy's pairwise sum for n < 128 (numpy/_core/src/umath/loops_utils.h.src), needed so that
+// np.var of the gap list is reproduced to the bit
+__device__ __forceinline__ double wol_np_sum_small(const double* v, int n) {
+    if (n < 8) {
+        double r = -0.0;
+        for (int i = 0; i < n; ++i) r += v[i];
+        return r;
+    }
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = v[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] += v[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += v[i];
+    return res;
+}
+
+#define WOL_LSI_CAP 96  // shell + 1 distances per water held in scratch (the 3.7 A shell has ~5-8)
+
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_lsi(ShellArgs a, double high2sq, double* __restrict__ scratch, double* __restrict__ lsi_full,
+      double* __restrict__ num_lsi, int* __restrict__ overflow) {
+    const int q = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (q >= a.ns) return;
+    double c[3];
+    int row;
+    wol_shell_query(a, q, c, &row);
+    double* __restrict__ dist = scratch + (int64_t)q * WOL_LSI_CAP;
+    const FrameGrid& g = *a.grid;
+    int k = 0;
+    bool have_next = false;
+    double next_raw = 0.0, next_d2 = 0.0;
+    int next_idx = 0x7fffffff;
+    wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
+        if (d2 > a.lowsq && d2 <= a.highsq) {
+            if (k < WOL_LSI_CAP - 1) dist[k] = sqrt(d2);  // lsiDists, waterlib.f90:916
+            ++k;
+        }
+        if (d2 > a.highsq && d2 <= high2sq) {
+            // wp:289-291: the "next" neighbour is picked by its RAW (not minimum-image) distance;
+            // np.argmin keeps the first minimum in ascending original index
+            const double4 p = a.sorted[slot];
+            const double rx = p.x - c[0], ry = p.y - c[1], rz = p.z - c[2];
+            const double raw = sqrt(wol_sumsq(rx, ry, rz));
+            const int idx = (int)__double_as_longlong(p.w);
+            if (!have_next || raw < next_raw || (raw == next_raw && idx < next_idx)) {
+                have_next = true; next_raw = raw; next_idx = idx; next_d2 = d2;
+            }
+        }
+    });
+    (void)g;
+    double res = __builtin_nan("");
+    double cnt = 0.0;
+    if (k >= WOL_LSI_CAP - 1) {
+        atomicExch(overflow, 1);
+    } else if (k > 1 && have_next) {
+        dist[k] = sqrt(next_d2);
+        const int m = k + 1;
+        for (int i = 1; i < m; ++i) {  // np.sort
+            const double x = dist[i];
+            int p = i;
+            while (p > 0 && dist[p - 1] > x) { dist[p] = dist[p - 1]; --p; }
+            dist[p] = x;
+        }
+        for (int i = 0; i < m - 1; ++i) dist[i] = dist[i + 1] - dist[i];  // successive gaps
+        const int nd = m - 1;
+        const double mean = wol_np_sum_small(dist, nd) / (double)nd;  // np.var (ddof = 0)
+        for (int i = 0; i < nd; ++i) { const double x = dist[i] - mean; dist[i] = x * x; }
+        res = wol_np_sum_small(dist, nd) / (double)nd;
+        cnt = (double)nd;
+    }
+    lsi_full[row] = res;
+    num_lsi[row] = cnt;
+}
