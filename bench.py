@@ -73,10 +73,10 @@ def cpu_baseline(pos_host, box, sample_waters, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--waters", type=int, default=100000)
-    ap.add_argument("--frames-per-step", type=int, default=100)
+    ap.add_argument("--frames-per-step", type=int, default=256)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--cell-width", type=float, default=0.0)
     ap.add_argument("--path", type=int, default=0)

@@ -165,6 +165,21 @@ def test_traj_golden_and_oracle(oracle):
     assert res.dhist.sum() == 4 * 5000 * 12
 
 
+def test_traj_lds_sort_batch(oracle):
+    """>= 128 frames per batch switches the cell sort to the one-block-per-frame LDS kernel"""
+    from waterorderlib_amd import engine, synth, _lib
+    xyz, boxes = synth.water_frames(1200, 130, seed=79)
+    a = engine.tet_order_traj(xyz, boxes, want_q=True)
+    ctx = _lib.Context(0)
+    ctx.set_option("lds_sort", 0)
+    b = engine.tet_order_traj(xyz, boxes, want_q=True, ctx=ctx)
+    assert np.array_equal(a.q, b.q) and np.array_equal(a.qhist, b.qhist) and np.array_equal(a.dhist, b.dhist)
+    assert np.array_equal(a.mean, b.mean) and np.array_equal(a.var, b.var)
+    q = oracle.getOrderParamq(xyz[77], xyz[77], boxes[77])
+    np.testing.assert_allclose(a.q[77], q, rtol=0, atol=Q_TOL)
+    ctx.close()
+
+
 def test_traj_device_resident_matches_host():
     import torch
     from waterorderlib_amd import engine, synth

@@ -76,13 +76,15 @@ struct PinBuf {
 struct wol_ctx {
     int device = 0;
     int num_cus = 256;
+    size_t sort_lds_set = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // options
-    double cell_width = 5.0;
+    double cell_width = 4.5;
     int frames_per_batch = 0;
     int path = 0;
     bool time_kernels = false;
+    bool lds_sort = true;
     // workspace
     DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
@@ -179,10 +181,13 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
         g->tmax = 8388608.0f + (float)(kunits - 1.0);
         // fp32 error of a key: staged coordinates are rounded once (half an ulp at the largest local
         // magnitude M), differences of two such numbers are exact, the three fmas round to integers
-        // (x is kept relative to the box origin until it is staged, so M is the box length there)
-        const double ext = std::fmax(box[0] + g->cw[0], std::fmax((g->ry + 2) * g->cw[1], 3.0 * g->cw[2]));
+        // (staged coordinates are cell-local values plus a cell offset, centred on the tile: M is half
+        // the halo'd tile extent)
+        const double ext = std::fmax(0.5 * (g->sx + 2) * g->cw[0], std::fmax(0.5 * (g->ry + 2) * g->cw[1], 1.5 * g->cw[2]))
+                           + std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double M = ext * g->scale;
         const double ulpM = std::ldexp(1.0, (int)std::ceil(std::log2(M)) - 24);
+        // two roundings per staged coordinate (cell-local value, then + offset), two coordinates per difference
         const double eps = 2.0 * 1.7320508 * (rmax * g->scale) * (2.0 * ulpM) + 1.5;
         g->eps_units = (int)std::ceil(eps * 1.25) + 2;
         g->fast_ok = (high >= rmax) ? 1 : 0;
@@ -293,7 +298,6 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         if (!c->grid_ev) HIP_TRY(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
         c->grid_copy_pending = true;
-        HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)cell_total, c->stream));
         bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
         int tiles_max = 0;
         for (int f = 0; f < F && use_fast; ++f) {
@@ -307,12 +311,31 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             WOL_TRY(c->sorted32.ensure(sizeof(float4) * (size_t)F * n));
             s32 = c->sorted32.as<float4>();
         }
-        const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
-        hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
-        hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
-        hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                           c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>(), s32);
+        // sort: one block per frame with the cell counters in LDS when the batch can fill the chip that
+        // way (a block moves ~24 GB/s, one CU's share, so it needs >= ~128 frames to beat the global-
+        // atomic form) and every frame's table fits; else the count / scan / scatter kernels
+        int ncell_max = 0;
+        for (int f = 0; f < F; ++f) ncell_max = std::max(ncell_max, gh[f].ncell);
+        const size_t sort_lds = sizeof(int) * ((size_t)ncell_max + 1);
+        const bool lds_sort = F >= 128 && sort_lds + sizeof(int) * WOL_SORT_BLOCK + 1024 <= 160 * 1024 && c->lds_sort;
+        if (lds_sort) {
+            if (sort_lds > c->sort_lds_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_frame_lds<T>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(int) * WOL_SORT_BLOCK - 1024)));
+                c->sort_lds_set = 160 * 1024;
+            }
+            hipLaunchKernelGGL(k_sort_frame_lds<T>, dim3(F), dim3(WOL_SORT_BLOCK), sort_lds, c->stream, fv,
+                               c->grids.as<FrameGrid>(), c->cells.as<int>(), c->rank.as<int>(),
+                               c->sorted.as<double4>(), s32);
+        } else {
+            HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)cell_total, c->stream));
+            const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
+            hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                               c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
+            hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
+                               c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>(), s32);
+        }
 
         SearchArgs a;
         a.grids = c->grids.as<FrameGrid>();
@@ -362,9 +385,12 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
             const int64_t wtotal = (int64_t)F * n;
             int ggrid = 0;
-            WOL_TRY(resident_grid(c, k_finish_fast, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            const bool lean = fa.fast_q && !out.nn_idx && !out.nn_dist;
+            if (lean) WOL_TRY(resident_grid(c, k_finish_fast<true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            else WOL_TRY(resident_grid(c, k_finish_fast<false>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             if (fa.xcd_affine) ggrid = std::max(8, (ggrid / 8) * 8);
-            hipLaunchKernelGGL(k_finish_fast, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            if (lean) hipLaunchKernelGGL(k_finish_fast<true>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            else hipLaunchKernelGGL(k_finish_fast<false>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             int lgrid = 0;
             WOL_TRY(resident_grid(c, k_search_exact_list, WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
             hipLaunchKernelGGL(k_search_exact_list, dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
@@ -628,6 +654,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
     } else if (k == "path") {
         if (value < 0 || value > 3) return fail(WOL_ERR_INVALID, "path must be 0..3");
         c->path = (int)value;
+    } else if (k == "lds_sort") {
+        c->lds_sort = value != 0.0;
     } else if (k == "time_kernels") {
         c->time_kernels = value != 0.0;
     } else {

@@ -89,17 +89,125 @@ k_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __re
     v.w = __longlong_as_double((long long)i);
     sorted[o + dst] = v;
     if (sorted32) {
-        // fp32 copy for the filtered search, already in key units: x = wrapped coordinate from the box
-        // origin, y and z = position inside the own cell (a staged row has one y and one z cell)
+        // fp32 copy for the filtered search, already in key units: position inside the own cell (the
+        // staging adds the cell's offset in the tile frame, so magnitudes -- and rounding -- stay small)
         const int nx = g.nc[0], ny = g.nc[1];
-        const int cy = (cell / nx) % ny, cz = cell / (nx * ny);
+        const int cx = cell % nx, cy = (cell / nx) % ny, cz = cell / (nx * ny);
         double u;
         float4 w;
-        u = v.x * g.box.ib[0]; u -= floor(u); w.x = (float)(u * (double)nx * g.cw[0] * (double)g.scale);
+        u = v.x * g.box.ib[0]; u -= floor(u); w.x = (float)((u * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
         u = v.y * g.box.ib[1]; u -= floor(u); w.y = (float)((u * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
         u = v.z * g.box.ib[2]; u -= floor(u); w.z = (float)((u * (double)g.nc[2] - (double)cz) * g.cw[2] * (double)g.scale);
         w.w = 0.f;
         sorted32[o + dst] = w;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused counting sort of ONE frame per 1024-thread block, cell counters in LDS (dynamic, ncell+1
+// ints, up to the CU's 160 KiB): count with LDS atomics (the global-atomic form above is bound by
+// the ~33 G/s rate of memory-side atomics), block scan in place, scatter.  Used when a batch has
+// enough frames to fill the chip with one block each and the cell table fits.
+// ---------------------------------------------------------------------------------------------
+#define WOL_SORT_BLOCK 1024
+template <typename T>
+__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ cell_start,
+                 int* __restrict__ rank, double4* __restrict__ sorted, float4* __restrict__ sorted32) {
+    extern __shared__ int cnt[];          // [ncell + 1]
+    __shared__ int part[WOL_SORT_BLOCK];
+    const int f = blockIdx.x;
+    const FrameGrid& g = grids[f];
+    const int ncell = g.ncell, tid = threadIdx.x;
+    const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
+    const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
+    int* __restrict__ rk = rank + (int64_t)f * fv.n;
+    for (int c = tid; c <= ncell; c += WOL_SORT_BLOCK) cnt[c] = 0;
+    __syncthreads();
+    // ---- pass 1: cell of every water, arrival rank inside the cell (8 waters per thread in flight:
+    //      one block owns the whole frame, so memory-level parallelism has to come from unrolling) ----
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
+        double x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < fv.n) {
+                const T* p = base + (int64_t)i * fv.atom_stride;
+                x[u] = (double)p[0]; y[u] = (double)p[1]; z[u] = (double)p[2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < fv.n) {
+                const int cx = wol_cell_coord(x[u], g.box.ib[0], nx, nullptr);
+                const int cy = wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
+                const int cz = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr);
+                rk[i] = atomicAdd(&cnt[(cz * ny + cy) * nx + cx], 1);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan of the counters in place ----
+    const int per = (ncell + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
+    const int b = min(tid * per, ncell), e = min(b + per, ncell);
+    int s = 0;
+    for (int k = b; k < e; ++k) s += cnt[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int k = b; k < e; ++k) { const int v = cnt[k]; cnt[k] = run; run += v; }
+    if (tid == WOL_SORT_BLOCK - 1) cnt[ncell] = part[WOL_SORT_BLOCK - 1];
+    __syncthreads();
+    int* __restrict__ cs = cell_start + g.cell_base;
+    for (int c = tid; c <= ncell; c += WOL_SORT_BLOCK) cs[c] = cnt[c];
+    // ---- pass 2: scatter (coordinates re-read; they are still in L2 / Infinity Cache) ----
+    double4* __restrict__ so = sorted + (int64_t)f * fv.n;
+    float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * fv.n : nullptr;
+    for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
+        double x[U], y[U], z[U];
+        int r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < fv.n) {
+                const T* p = base + (int64_t)i * fv.atom_stride;
+                x[u] = (double)p[0]; y[u] = (double)p[1]; z[u] = (double)p[2];
+                r[u] = rk[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i >= fv.n) continue;
+            double4 v;
+            v.x = x[u]; v.y = y[u]; v.z = z[u];
+            v.w = __longlong_as_double((long long)i);
+            double ux = v.x * g.box.ib[0]; ux -= floor(ux);
+            double uy = v.y * g.box.ib[1]; uy -= floor(uy);
+            double uz = v.z * g.box.ib[2]; uz -= floor(uz);
+            // same arithmetic as wol_cell_coord
+            int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);
+            int cy = (int)(uy * (double)ny); cy = cy >= ny ? ny - 1 : (cy < 0 ? 0 : cy);
+            int cz = (int)(uz * (double)nz); cz = cz >= nz ? nz - 1 : (cz < 0 ? 0 : cz);
+            const int dst = cnt[(cz * ny + cy) * nx + cx] + r[u];
+            so[dst] = v;
+            if (so32) {
+                float4 w;
+                w.x = (float)((ux * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
+                w.y = (float)((uy * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
+                w.z = (float)((uz * (double)nz - (double)cz) * g.cw[2] * (double)g.scale);
+                w.w = 0.f;
+                so32[dst] = w;
+            }
+        }
     }
 }
 

@@ -325,11 +325,10 @@ k_search_fast(FastArgs a) {
                 const int zi = (r >= rpl) + (r >= 2 * rpl), yi = r - zi * rpl;
                 const int src = cellsrc[r * WOL_CP + k], cnt = cellcnt[r * WOL_CP + k];
                 const int pos = cellpos[r * WOL_CP + k];
-                // x: wrapped coordinate from the box origin -> tile frame (halo images shifted)
-                float offx = -(float)x0 * fx;
-                if (k == 0 && x0 == 0) offx -= (float)nx * fx;
-                if (k == ncr - 1 && x0 + sxe == nx) offx += (float)nx * fx;
-                const float offy = (float)(yi - 1) * fy, offz = (float)(zi - 1) * fz;
+                // cell-local coordinates -> tile frame centred on the tile (periodic images of the halo
+                // cells come out shifted automatically: the offset is in staged-cell units)
+                const float offx = ((float)(k - 1) - 0.5f * (float)sxe) * fx;
+                const float offy = ((float)(yi - 1) - 0.5f * (float)re) * fy, offz = (float)(zi - 1) * fz;
                 for (int e0 = 0; e0 < cnt; e0 += 6) {
                     float4 v[6];
 #pragma unroll
@@ -431,6 +430,7 @@ k_search_fast(FastArgs a) {
 // 4th distance is inside the radius the 27-cell stencil guarantees (and agrees with the fp32 key),
 // computes angles / q / histograms; everything else goes to the exact list.
 // ---------------------------------------------------------------------------------------------
+template <bool LEAN>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_finish_fast(FastArgs a) {
     extern __shared__ int lds_hist[];
@@ -439,6 +439,8 @@ k_finish_fast(FastArgs a) {
     if (lds_qh) wol_hist_zero(lds_qh, a.out.qbins);
     if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
     __syncthreads();
+    constexpr bool lean = LEAN;  // host: fast_q && no per-neighbour outputs
+    const double dinv = (a.out.dbinwidth > 0.0) ? 1.0 / a.out.dbinwidth : 0.0;
     // frames <-> XCDs as in the proposal kernel, so a frame's sorted array is read through one L2
     const bool aff = a.xcd_affine != 0;
     const int fstep = aff ? 8 : 1;
@@ -452,7 +454,80 @@ k_finish_fast(FastArgs a) {
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
         const int kd3 = a.prop_key[w];
         bool slow = kd3 < 0;
-        if (!slow) {
+        if constexpr (LEAN) { if (!slow) {
+            // ---- lean path (trajectory mode: q, histograms, no per-neighbour outputs): the four
+            //      proposed neighbours are certified and q is formed from their min-image vectors in
+            //      proposal order -- no ranking, no second re-image, shared norms ----
+            const int4 pr = a.prop[w];
+            const double4 mev = sp[s];
+            const double c[3] = {mev.x, mev.y, mev.z};
+            const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
+            double vx[4], vy[4], vz[4], dist[4];
+            double dmax = 0.0, emax = 0.0;
+            bool all_in = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double dx = wol_minimg1(nb[k].x - c[0], g.box.L[0], g.box.ib[0]);   // waterlib.f90:733-735
+                const double dy = wol_minimg1(nb[k].y - c[1], g.box.L[1], g.box.ib[1]);
+                const double dz = wol_minimg1(nb[k].z - c[2], g.box.L[2], g.box.ib[2]);
+                const double d2 = wol_sumsq(dx, dy, dz);
+                all_in = all_in && (d2 > 0.0) && (d2 <= a.highsq);
+                const double px = c[0] + dx, py = c[1] + dy, pz = c[2] + dz;              // reimage (wp:372)
+                vx[k] = px - c[0]; vy[k] = py - c[1]; vz[k] = pz - c[2];                  // thisPos - apos (wp:373)
+                dist[k] = sqrt(wol_sumsq(vx[k], vy[k], vz[k]));
+                dmax = fmax(dmax, dist[k]);
+                emax = fmax(emax, fmax(fabs(vx[k]) * g.box.ib[0], fmax(fabs(vy[k]) * g.box.ib[1], fabs(vz[k]) * g.box.ib[2])));
+            }
+            double rg = __builtin_huge_val();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double fr;
+                (void)wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr);
+                rg = fmin(rg, g.cw[k] + fmin(fr, 1.0 - fr) * g.cw[k]);
+            }
+            rg -= 1e-6;
+            const double d3s = (dmax * dmax) * g.S;
+            // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity, so the
+            // vectors CosAngle3 sees are exactly (apos + v) - apos
+            if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)g.eps_units || !(emax < 0.49)) {
+                slow = true;
+            } else {
+                double wx[4], wy[4], wz[4], rn[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    wx[k] = (c[0] + vx[k]) - c[0]; wy[k] = (c[1] + vy[k]) - c[1]; wz[k] = (c[2] + vz[k]) - c[2];
+                    rn[k] = rsqrt(wol_sumsq(wx[k], wy[k], wz[k]));
+                }
+                double ssum = -0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = i + 1; j < 4; ++j) {
+                        const double dot = (wx[i] * wx[j] + wy[i] * wy[j]) + wz[i] * wz[j];
+                        const double cs_ = fmin(1.0, fmax(-1.0, dot * (rn[i] * rn[j]))) + (1.0 / 3.0);
+                        ssum += cs_ * cs_;
+                    }
+                const double q = 1.0 - (3.0 / 8.0) * ssum;
+                const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
+                if (a.out.q) a.out.q[orow] = q;
+                if (a.out.q32) a.out.q32[orow] = (float)q;
+                if (lds_qh) {
+                    const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
+                    if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
+                }
+                if (lds_dh) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal and
+                        // take the true division only when the product sits on an integer
+                        const double tq = dist[k] * dinv;
+                        double cb = ceil(tq);
+                        if (fabs(tq - rint(tq)) < 1e-9 * tq) cb = ceil(dist[k] / a.out.dbinwidth);
+                        if (cb >= 1.0 && cb <= (double)a.out.dbins) atomicAdd(&lds_dh[(int)cb - 1], 1);
+                    }
+                }
+            }
+        } } else if (!slow) {
             const int4 pr = a.prop[w];
             const double4 mev = sp[s];
             const double c[3] = {mev.x, mev.y, mev.z};
