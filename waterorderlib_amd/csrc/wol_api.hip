@@ -146,34 +146,45 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
 
     // ---- tiling for the filtered kernel (wol_search_fast.hip) ----
     g->fast_ok = 0;
-    g->sx = g->ry = g->ntx = g->nty = 1;
+    g->sx = g->ry = g->sz = g->ntx = g->nty = g->ntz = 1;
     g->ntiles = 0;
     g->scale = 1.f; g->tmax = 0.f; g->S = 1.0; g->eps_units = 0;
     if (g->nc[0] >= 3 && g->nc[1] >= 3 && g->nc[2] >= 3) {
         const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
         const double wpc = std::fmax((double)n / (double)g->ncell, 0.05);
-        // tile = sx x ry cells of one z layer: as many waters as fit one sweep of the block (one lane
-        // per water, ~7 % head-room) while the halo'd tile (3 layers of (ry+2) x (sx+2) cells, each
-        // padded to an even count, +15 %) fits the LDS pair buffer; all tiles of a frame equal-sized
+        // tile = sx x ry x sz cells: as many waters as fit one sweep of the block (one lane per water,
+        // ~7 % head-room) while the halo'd tile ((sz+2) layers of (ry+2) x (sx+2) cells, each padded to an
+        // even count, +15 %) fits the LDS pair buffer and the row tables; among the fullest shapes the one
+        // with the smallest halo.  Tiles of a frame are equal-sized up to one cell per axis.
         double best = -1.0;
-        g->sx = 1; g->ry = 1; g->ntx = g->nc[0]; g->nty = g->nc[1];
+        g->sx = 1; g->ry = 1; g->sz = 1; g->ntx = g->nc[0]; g->nty = g->nc[1]; g->ntz = g->nc[2];
         for (int ntx = 1; ntx <= g->nc[0]; ++ntx) {
             const int sx = (g->nc[0] + ntx - 1) / ntx;
-            if (sx > WOL_FAST_MAXSX) continue;
-            if ((g->nc[0] + sx - 1) / sx != ntx) continue;
+            if (sx > WOL_FAST_MAXSX || (g->nc[0] + sx - 1) / sx != ntx) continue;
             for (int nty = 1; nty <= g->nc[1]; ++nty) {
                 const int ry = (g->nc[1] + nty - 1) / nty;
                 if (ry > WOL_FAST_MAXRY || (g->nc[1] + ry - 1) / ry != nty) continue;
-                const double q = sx * ry * wpc;
-                if (q > (double)WOL_FAST_TARGET && !(sx == 1 && ry == 1)) continue;
-                if (3.0 * (ry + 2) * (sx + 2) * (wpc + 0.5) * 1.15 > 2.0 * WOL_FAST_CAPP) continue;
-                // prefer full sweeps; among equals the squarer tile (smaller halo)
-                const double score = q - 0.01 * std::abs(sx - ry);
-                if (score > best) { best = score; g->sx = sx; g->ry = ry; g->ntx = ntx; g->nty = nty; }
+                for (int ntz = 1; ntz <= g->nc[2]; ++ntz) {
+                    const int sz = (g->nc[2] + ntz - 1) / ntz;
+                    if (sz > WOL_FAST_MAXSZ || (g->nc[2] + sz - 1) / sz != ntz) continue;
+                    if (sz * ry > WOL_FAST_MAXQROWS || (sz + 2) * (ry + 2) > WOL_FAST_MAXROWS) continue;
+                    const double q = sx * ry * sz * wpc;
+                    const bool unit = (sx == 1 && ry == 1 && sz == 1);
+                    if (q > (double)WOL_FAST_TARGET && !unit) continue;
+                    const double staged = (double)(sz + 2) * (ry + 2) * (sx + 2) * (wpc + 0.5);
+                    if (staged * 1.15 > 2.0 * WOL_FAST_CAPP && !unit) continue;
+                    // fill of the block's lanes first (5 % bands), then the halo ratio
+                    const double band = std::floor(q / (0.05 * WOL_FAST_TARGET));
+                    const double score = band - staged / (q * 100.0);
+                    if (score > best) {
+                        best = score;
+                        g->sx = sx; g->ry = ry; g->sz = sz; g->ntx = ntx; g->nty = nty; g->ntz = ntz;
+                    }
+                }
             }
         }
-        g->ntiles = g->ntx * g->nty * g->nc[2];
+        g->ntiles = g->ntx * g->nty * g->ntz;
         const double kunits = std::ldexp(1.0, 32 - WOL_ID_BITS);
         g->S = kunits / (rmax * rmax);                      // key units over [0, rmax^2)
         g->scale = (float)std::sqrt(g->S);
@@ -183,7 +194,7 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
         // magnitude M), differences of two such numbers are exact, the three fmas round to integers
         // (staged coordinates are cell-local values plus a cell offset, centred on the tile: M is half
         // the halo'd tile extent)
-        const double ext = std::fmax(0.5 * (g->sx + 2) * g->cw[0], std::fmax(0.5 * (g->ry + 2) * g->cw[1], 1.5 * g->cw[2]))
+        const double ext = std::fmax(0.5 * (g->sx + 2) * g->cw[0], std::fmax(0.5 * (g->ry + 2) * g->cw[1], 0.5 * (g->sz + 2) * g->cw[2]))
                            + std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double M = ext * g->scale;
         const double ulpM = std::ldexp(1.0, (int)std::ceil(std::log2(M)) - 24);

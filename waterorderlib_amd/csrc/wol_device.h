@@ -26,8 +26,8 @@ struct FrameGrid {
     int64_t cell_base;  // offset of this frame's cell_start[] in the batch array
     // ---- tiling of the filtered (fp32 + exact finish) search kernel ----
     int fast_ok;        // grid has >= 3 cells per axis and the cutoff covers the guaranteed radius
-    int sx, ry;         // tile = sx cells along x by ry rows along y in one z layer
-    int ntx, nty;       // tiles per axis (ntx*nty*nc[2] tiles per frame)
+    int sx, ry, sz;     // tile = sx cells along x by ry rows along y by sz layers along z
+    int ntx, nty, ntz;  // tiles per axis
     int ntiles;
     float scale;        // sqrt(S): staged coordinates are multiplied by it so d^2 comes out in key units
     float tmax;         // 2^23 + 2^21 - 1: saturation of the biased squared distance

@@ -30,6 +30,8 @@
 #define WOL_FAST_PADP 40      // head-room (pairs) incl. the dummy pair
 #define WOL_FAST_MAXROWS 96   // 3*(ry+2) <= 96
 #define WOL_FAST_MAXRY 30
+#define WOL_FAST_MAXSZ 4
+#define WOL_FAST_MAXQROWS 64   // sz * ry rows of own waters
 #define WOL_FAST_MAXSX 12
 #define WOL_CP 16             // row stride of the cell tables: sx + 3 <= 15
 #define WOL_FAST_MAXCELL 20   // a cell with more waters sends its tile to the exact path (span <= 64 entries)
@@ -197,8 +199,8 @@ k_search_fast(FastArgs a) {
     __shared__ unsigned short cellpos[WOL_FAST_MAXROWS * WOL_CP];   // staged cell -> first entry (even)
     __shared__ unsigned char cellcnt[WOL_FAST_MAXROWS * WOL_CP];    // staged cell -> waters in it
     __shared__ int rowlen[WOL_FAST_MAXROWS];
-    __shared__ int qrow[WOL_FAST_MAXRY + 2];                        // own rows -> first query number
-    __shared__ int s_flag;
+    __shared__ int qrow[WOL_FAST_MAXQROWS + 2];                     // own rows -> first query number
+    __shared__ int s_flag, s_total;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
 #ifdef WOL_PHASE_STAMPS
@@ -218,16 +220,19 @@ k_search_fast(FastArgs a) {
         const FrameGrid& g = a.grids[f];
         if (tile >= g.ntiles || g.maxshell < 0 || !g.fast_ok) continue;  // uniform over the block
         const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
-        // tile -> (tx, ty, cz) through float reciprocals (exact for these small operands)
+        // tile -> (tx, ty, tz) through float reciprocals (exact for these small operands)
         const int ntxy = g.ntx * g.nty;
-        const int cz = (int)(((float)tile + 0.5f) / (float)ntxy);
-        const int trem = tile - cz * ntxy;
+        const int tz = (int)(((float)tile + 0.5f) / (float)ntxy);
+        const int trem = tile - tz * ntxy;
         const int ty = (int)(((float)trem + 0.5f) / (float)g.ntx);
         const int tx = trem - ty * g.ntx;
         const int x0 = tx * g.sx, sxe = min(g.sx, nx - x0);
         const int y0 = ty * g.ry, re = min(g.ry, ny - y0);
+        const int z0 = tz * g.sz, sze = min(g.sz, nz - z0);
         const int rpl = re + 2;           // staged rows per z layer
-        const int nrows = 3 * rpl, ncr = sxe + 2;
+        const int nrows = (sze + 2) * rpl, ncr = sxe + 2;
+        const int nqr = sze * re;         // rows holding the tile's own waters
+        const float inv_rpl = 1.0f / (float)rpl, inv_re = 1.0f / (float)re;
         const float4* __restrict__ sp32 = a.sorted32 + (int64_t)f * a.n;
         const int* __restrict__ cs = a.cell_start + g.cell_base;
         const int64_t frame_off = (int64_t)f * a.n;
@@ -245,8 +250,8 @@ k_search_fast(FastArgs a) {
             for (int r = tid >> 4; r < ((nrows + 1) & ~1); r += WOL_FAST_BLOCK >> 4) {
                 int cnt = 0, src = 0;
                 if (r < nrows && k < ncr) {
-                    const int zi = (r >= rpl) + (r >= 2 * rpl), yi = r - zi * rpl;
-                    const int gz = wol_wrap_cell(cz + zi - 1, nz), gy = wol_wrap_cell(y0 + yi - 1, ny);
+                    const int zi = (int)(((float)r + 0.5f) * inv_rpl), yi = r - zi * rpl;
+                    const int gz = wol_wrap_cell(z0 + zi - 1, nz), gy = wol_wrap_cell(y0 + yi - 1, ny);
                     const int c = (gz * ny + gy) * nx + wol_wrap_cell(x0 + k - 1, nx);
 #ifdef WOL_EXP_NO_CS_LOAD   // ablation build: timing only, results are wrong
                     src = c * 2; cnt = 2 + (c & 1);
@@ -283,7 +288,7 @@ k_search_fast(FastArgs a) {
             }
             if (lane == 0) {
                 if (run > 2 * WOL_FAST_CAPP) s_flag = 1;
-                qrow[WOL_FAST_MAXRY + 1] = run;  // total entries incl. padding
+                s_total = run;  // total entries incl. padding
             }
         }
         __syncthreads();
@@ -295,25 +300,26 @@ k_search_fast(FastArgs a) {
             }
             cellpos[tid * WOL_CP + ncr] = (unsigned short)pos;
         }
-        // own rows: running number of the tile's waters (queries)
+        // own rows (layers 1..sze, rows 1..re): running number of the tile's waters (queries)
         if (wave == 1) {
             int c = 0;
-            if (lane < re) {
-                const int r = rpl + lane + 1;
+            if (lane < nqr) {
+                const int lz = (int)(((float)lane + 0.5f) * inv_re), ly = lane - lz * re;
+                const int r = (lz + 1) * rpl + ly + 1;
                 for (int k = 1; k <= sxe; ++k) c += cellcnt[r * WOL_CP + k];
             }
             int inc = c;
 #pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {
+            for (int off = 1; off < 64; off <<= 1) {
                 const int v = __shfl_up(inc, off, 64);
                 if (lane >= off) inc += v;
             }
-            if (lane < WOL_FAST_MAXRY) qrow[lane + 1] = inc;
+            qrow[lane + 1] = inc;
             if (lane == 0) qrow[0] = 0;
         }
         __syncthreads();
         const bool overflow = s_flag != 0;
-        const int total_e = qrow[WOL_FAST_MAXRY + 1];
+        const int total_e = s_total;
         const int dummy_p = (total_e >> 1) + WOL_FAST_PADP - 2;  // behind the read head-room
         WOL_STAMP(2);
         // ---- phase 3: stage.  16 lanes per row, one per cell: two waters at a time become one pair
@@ -322,13 +328,14 @@ k_search_fast(FastArgs a) {
             const int k = tid & 15;
             for (int r = tid >> 4; r < nrows; r += WOL_FAST_BLOCK >> 4) {
                 if (k >= ncr) continue;
-                const int zi = (r >= rpl) + (r >= 2 * rpl), yi = r - zi * rpl;
+                const int zi = (int)(((float)r + 0.5f) * inv_rpl), yi = r - zi * rpl;
                 const int src = cellsrc[r * WOL_CP + k], cnt = cellcnt[r * WOL_CP + k];
                 const int pos = cellpos[r * WOL_CP + k];
                 // cell-local coordinates -> tile frame centred on the tile (periodic images of the halo
                 // cells come out shifted automatically: the offset is in staged-cell units)
                 const float offx = ((float)(k - 1) - 0.5f * (float)sxe) * fx;
-                const float offy = ((float)(yi - 1) - 0.5f * (float)re) * fy, offz = (float)(zi - 1) * fz;
+                const float offy = ((float)(yi - 1) - 0.5f * (float)re) * fy;
+                const float offz = ((float)(zi - 1) - 0.5f * (float)sze) * fz;
                 for (int e0 = 0; e0 < cnt; e0 += 6) {
                     float4 v[6];
 #pragma unroll
@@ -367,17 +374,20 @@ k_search_fast(FastArgs a) {
             }
         }
         __syncthreads();
-        const int nq = qrow[re];
+        const int nq = qrow[nqr];
         WOL_STAMP(3);
 
         for (int qb = wave * 64; qb < nq; qb += WOL_FAST_BLOCK) {
             const int qi = qb + lane;
             if (qi >= nq) continue;
-            int ly = 0;
-            while (ly + 1 < re && qrow[ly + 1] <= qi) ++ly;
-            const int rq = rpl + ly + 1;
+            int qr = 0;  // own row of this water: largest qr with qrow[qr] <= qi (binary search, nqr <= 64)
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                if (qr + step < nqr && qrow[qr + step] <= qi) qr += step;
+            const int lz = (int)(((float)qr + 0.5f) * inv_re), ly = qr - lz * re;
+            const int rq = (lz + 1) * rpl + ly + 1;
             // own cell and entry: walk the row's cells
-            int lx = 0, left = qi - qrow[ly];
+            int lx = 0, left = qi - qrow[qr];
             while (lx + 1 < sxe && left >= (int)cellcnt[rq * WOL_CP + lx + 1]) { left -= cellcnt[rq * WOL_CP + lx + 1]; ++lx; }
             const int self_slot = cellsrc[rq * WOL_CP + lx + 1] + left;
             int4 prop;
@@ -395,7 +405,7 @@ k_search_fast(FastArgs a) {
                 for (int dzi = 0; dzi < 3; ++dzi) {
 #pragma unroll
                     for (int dyi = 0; dyi < 3; ++dyi) {
-                        const int r = dzi * rpl + ly + dyi;
+                        const int r = (lz + dzi) * rpl + ly + dyi;
                         const int pb = cellpos[r * WOL_CP + lx] >> 1, pe = cellpos[r * WOL_CP + lx + 3] >> 1;
                         if (dzi == 1 && dyi == 1)
                             wol_fast_span<true>(reinterpret_cast<const char*>(rec), pb, pe - pb, dummy_p * 32, xi, yi, zi, (unsigned)self_e, tmaxbits, k0, k1, k2, k3, k4);
@@ -498,15 +508,31 @@ k_finish_fast(FastArgs a) {
                     wx[k] = (c[0] + vx[k]) - c[0]; wy[k] = (c[1] + vy[k]) - c[1]; wz[k] = (c[2] + vz[k]) - c[2];
                     rn[k] = rsqrt(wol_sumsq(wx[k], wy[k], wz[k]));
                 }
+                // the six terms are summed in ascending order of their values: the result must not depend
+                // on the order in which the proposal lists the neighbours (which can follow the arrival
+                // order of waters inside a cell when two fp32 keys tie)
+                double tm[6];
+                {
+                    int m = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = i + 1; j < 4; ++j) {
+                            const double dot = (wx[i] * wx[j] + wy[i] * wy[j]) + wz[i] * wz[j];
+                            const double cs_ = fmin(1.0, fmax(-1.0, dot * (rn[i] * rn[j]))) + (1.0 / 3.0);
+                            tm[m++] = cs_ * cs_;
+                        }
+                }
+#define WOL_CE(i, j) { const double lo_ = fmin(tm[i], tm[j]), hi_ = fmax(tm[i], tm[j]); tm[i] = lo_; tm[j] = hi_; }
+                WOL_CE(0, 5) WOL_CE(1, 3) WOL_CE(2, 4)   // 12-comparator sorting network for 6 keys
+                WOL_CE(1, 2) WOL_CE(3, 4)
+                WOL_CE(0, 3) WOL_CE(2, 5)
+                WOL_CE(0, 1) WOL_CE(2, 3) WOL_CE(4, 5)
+                WOL_CE(1, 2) WOL_CE(3, 4)
+#undef WOL_CE
                 double ssum = -0.0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = i + 1; j < 4; ++j) {
-                        const double dot = (wx[i] * wx[j] + wy[i] * wy[j]) + wz[i] * wz[j];
-                        const double cs_ = fmin(1.0, fmax(-1.0, dot * (rn[i] * rn[j]))) + (1.0 / 3.0);
-                        ssum += cs_ * cs_;
-                    }
+                for (int m = 0; m < 6; ++m) ssum += tm[m];
                 const double q = 1.0 - (3.0 / 8.0) * ssum;
                 const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
                 if (a.out.q) a.out.q[orow] = q;
