@@ -24,11 +24,14 @@
 #define WOL_FAST_BLOCK 512    // waves of a block share one staged tile; each sweeps one batch of 64 waters
 #endif
 #ifndef WOL_FAST_CAPP
-#define WOL_FAST_CAPP 1280    // staged PAIRS per tile (cells are padded to an even count)
+#define WOL_FAST_CAPP 1024    // staged PAIRS per tile (cells are padded to an even count); with the tables
+                              // this keeps a block under 53 KiB of LDS: three blocks (24 waves) per CU
 #endif
 #define WOL_FAST_TARGET ((WOL_FAST_BLOCK * 93) / 100)  // waters per tile aimed at (one lane each)
 #define WOL_FAST_PADP 40      // head-room (pairs) incl. the dummy pair
-#define WOL_FAST_MAXROWS 96   // 3*(ry+2) <= 96
+#ifndef WOL_FAST_MAXROWS
+#define WOL_FAST_MAXROWS 96   // (sz+2)*(ry+2) <= 96
+#endif
 #define WOL_FAST_MAXRY 30
 #define WOL_FAST_MAXSZ 4
 #define WOL_FAST_MAXQROWS 64   // sz * ry rows of own waters
@@ -191,7 +194,10 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
 // Writes per water (indexed by its slot in the sorted array) the sorted slots of the four proposed
 // neighbours and the 4th key (or -1 when the proposal cannot be certified by keys alone).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WOL_FAST_BLOCK)
+#ifndef WOL_FAST_WPS
+#define WOL_FAST_WPS 6   // waves per SIMD the register allocation must allow (3 blocks x 8 waves / 4 SIMDs)
+#endif
+__global__ void __launch_bounds__(WOL_FAST_BLOCK, WOL_FAST_WPS)
 k_search_fast(FastArgs a) {
     __shared__ float4 rec[2 * (WOL_FAST_CAPP + WOL_FAST_PADP)];     // pair records
     __shared__ int slot[2 * WOL_FAST_CAPP];                         // entry -> slot in the sorted array
