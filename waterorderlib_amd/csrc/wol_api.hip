@@ -86,7 +86,7 @@ struct wol_ctx {
     bool time_kernels = false;
     bool lds_sort = true;
     // workspace
-    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, slow_list, slow_count, prop, prop_key, stamps;
+    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, stat, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -419,7 +419,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         std::pair<hipEvent_t, hipEvent_t> ev;
         if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
         hipLaunchKernelGGL(k_brute_q<T>, dim3((ns + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), hist_lds,
-                           c->stream, pv, sv, b, lowsq, highsq, out, (int64_t)f * ns);
+                           c->stream, pv, sv, b, lowsq, highsq, out, (int64_t)f * ns, f);
         if (c->time_kernels) WOL_TRY(end_timing(c, ev));
     }
     HIP_TRY(hipGetLastError());
@@ -542,11 +542,11 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         double* qd = nullptr;
         if (q_direct) {
             qd = reinterpret_cast<double*>(q_out) + (int64_t)f0 * n;
-        } else if (need_stats || q_out) {
+        } else if (q_out && std::is_same<T, double>::value) {
             WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)F * n));
             qd = c->qbuf.as<double>();
         }
-        out.q = qd;
+        out.q = qd;  // per-water q is only materialised when the caller asks for it
         float* q32d = nullptr;
         if (q_out && !std::is_same<T, double>::value) {
             if (host) {
@@ -559,11 +559,17 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         out.q32 = q32d;
         out.qhist = d_qh; out.qbins = qbins;
         out.dhist = d_dh; out.dbins = dbins; out.dbinwidth = dbinwidth;
+        if (need_stats) {
+            WOL_TRY(c->stat.ensure(sizeof(unsigned long long) * 4 * (size_t)F));
+            HIP_TRY(hipMemsetAsync(c->stat.p, 0, sizeof(unsigned long long) * 4 * (size_t)F, c->stream));
+            out.stat = c->stat.as<unsigned long long>();
+        }
         WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out));
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
             double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
-            hipLaunchKernelGGL(k_frame_stats, dim3(F), dim3(1024), 0, c->stream, qd, n, dm, dv);
+            hipLaunchKernelGGL(k_stat_finalize, dim3((F + 255) / 256), dim3(256), 0, c->stream,
+                               c->stat.as<unsigned long long>(), F, n, dm, dv);
         }
         if (host && q_out) {
             if (std::is_same<T, double>::value)
@@ -629,7 +635,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->sorted, &c->sorted32, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);

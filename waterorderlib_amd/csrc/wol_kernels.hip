@@ -224,12 +224,49 @@ struct QOut {
     unsigned long long* dhist;  // [dbins] or null
     int qbins, dbins;
     double dbinwidth;
+    // per-frame sums of q and q^2 as exact fixed-point integers, [F][4] = {q_hi, q_lo, q2_hi, q2_lo}:
+    // value = hi * 2^-30 + lo * 2^-70.  Integer addition is associative, so mean/var do not depend on
+    // the order in which waters arrive (the cell sort's arrival ranks are not reproducible).  Or null.
+    unsigned long long* stat;
 };
+
+// q (or q^2) -> (hi, lo) with x = hi * 2^-30 + lo * 2^-70, hi = floor(x * 2^30) (two's complement for
+// negative q), 0 <= lo < 2^40.  Exact for |x| >= 2^-22, truncated below 2^-70 otherwise.
+__device__ __forceinline__ void wol_fix_split(double x, long long* hi, long long* lo) {
+    const double t = x * 1073741824.0;            // 2^30, exact scaling
+    const double fl = floor(t);
+    *hi = (long long)fl;
+    *lo = (long long)((t - fl) * 1099511627776.0);  // 2^40
+}
+
+// rare paths: one lane adds its water straight to the frame's accumulators
+__device__ __forceinline__ void wol_stat_add_lane(const QOut& o, int f, double q) {
+    if (!o.stat) return;
+    long long h, l, h2, l2;
+    wol_fix_split(q, &h, &l);
+    wol_fix_split(q * q, &h2, &l2);
+    unsigned long long* a = o.stat + 4 * (size_t)f;
+    atomicAdd(&a[0], (unsigned long long)h); atomicAdd(&a[1], (unsigned long long)l);
+    atomicAdd(&a[2], (unsigned long long)h2); atomicAdd(&a[3], (unsigned long long)l2);
+}
+
+// mean and population variance of every frame from the accumulators (np.mean / np.var, ddof = 0)
+__global__ void k_stat_finalize(const unsigned long long* __restrict__ stat, int F, int n,
+                                double* __restrict__ mean, double* __restrict__ var) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const long long* a = reinterpret_cast<const long long*>(stat) + 4 * (size_t)f;
+    const double s1 = (double)a[0] * 9.313225746154785e-10 + (double)a[1] * 8.470329472543003e-22;   // 2^-30, 2^-70
+    const double s2 = (double)a[2] * 9.313225746154785e-10 + (double)a[3] * 8.470329472543003e-22;
+    const double m = s1 / (double)n;
+    if (mean) mean[f] = m;
+    if (var) var[f] = s2 / (double)n - m * m;
+}
 
 // P* are the coordinates of the selected neighbours as stored (not yet re-imaged)
 __device__ __forceinline__ void wol_finish_water(const double a[3], const Top4& t, const double N0[3],
                                                  const double N1[3], const double N2[3], const double N3[3],
-                                                 const Box3& b, const QOut& o, int64_t slot,
+                                                 const Box3& b, const QOut& o, int64_t slot, int f,
                                                  int* __restrict__ lds_qh, int* __restrict__ lds_dh) {
     double P0[3] = {0, 0, 0}, P1[3] = {0, 0, 0}, P2[3] = {0, 0, 0}, P3[3] = {0, 0, 0};
     const int nb = t.n;
@@ -241,6 +278,7 @@ __device__ __forceinline__ void wol_finish_water(const double a[3], const Top4& 
     const double q = wol_q_from_points(a, P0, P1, P2, P3, nb, ang);
     if (o.q) o.q[slot] = q;
     if (o.q32) o.q32[slot] = (float)q;
+    wol_stat_add_lane(o, f, q);
     const double nanv = __builtin_nan("");
     if (o.nn_idx) {
         int4 v;
@@ -412,7 +450,7 @@ k_search_exact(SearchArgs a) {
         const double4 n0 = sp[t.s0], n1 = sp[t.s1], n2 = sp[t.s2], n3 = sp[t.s3];
         const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
         const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
-        wol_finish_water(c, t, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + out_row, lds_qh, lds_dh);
+        wol_finish_water(c, t, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + out_row, f, lds_qh, lds_dh);
     }
     __syncthreads();
     if (lds_qh) wol_hist_flush(lds_qh, a.out.qbins, a.out.qhist);
@@ -432,7 +470,7 @@ struct PointsView {
 template <typename T>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_brute_q(PointsView<T> pos, PointsView<T> sub, Box3 box, double lowsq, double highsq, QOut out,
-          int64_t out_base) {
+          int64_t out_base, int frame) {
     extern __shared__ int lds_hist[];
     __shared__ double tx[WOL_BLOCK], ty[WOL_BLOCK], tz[WOL_BLOCK];
     int* lds_qh = out.qhist ? lds_hist : nullptr;
@@ -475,7 +513,7 @@ k_brute_q(PointsView<T> pos, PointsView<T> sub, Box3 box, double lowsq, double h
             const T* p = pos.base + (int64_t)(k < t.n ? sl[k] : 0) * pos.stride;
             N[k][0] = (double)p[0]; N[k][1] = (double)p[1]; N[k][2] = (double)p[2];
         }
-        wol_finish_water(c, t, N[0], N[1], N[2], N[3], box, out, out_base + s, lds_qh, lds_dh);
+        wol_finish_water(c, t, N[0], N[1], N[2], N[3], box, out, out_base + s, frame, lds_qh, lds_dh);
     }
     __syncthreads();
     if (lds_qh) wol_hist_flush(lds_qh, out.qbins, out.qhist);
@@ -506,40 +544,6 @@ k_brute_mask(PointsView<double> pos, PointsView<double> sub, Box3 box, double lo
         const double dz = wol_minimg1(tz[k] - a2, box.L[2], box.ib[2]);
         const double d2 = wol_sumsq(dx, dy, dz);
         mask[(int64_t)i + (int64_t)(j0 + k) * sub.n] = (d2 > lowsq && d2 <= highsq) ? 1 : 0;
-    }
-}
-
-// =============================================================================================
-// per-frame statistics of q: np.mean and np.var (ddof=0) -- orderParam_lib.py:1473.
-// Fixed-order tree reduction => run-to-run bit-reproducible (numpy's pairwise order differs in
-// the last ulps; tests compare at 1e-12).
-// =============================================================================================
-__device__ __forceinline__ double wol_block_sum(double v, double* sm) {
-    const int tid = threadIdx.x;
-    sm[tid] = v;
-    __syncthreads();
-    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if (tid < off) sm[tid] += sm[tid + off];
-        __syncthreads();
-    }
-    const double r = sm[0];
-    __syncthreads();
-    return r;
-}
-
-__global__ void __launch_bounds__(1024)
-k_frame_stats(const double* __restrict__ q, int n, double* __restrict__ mean, double* __restrict__ var) {
-    __shared__ double sm[1024];
-    const double* qf = q + (int64_t)blockIdx.x * n;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) s += qf[i];
-    const double m = wol_block_sum(s, sm) / (double)n;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { const double d = qf[i] - m; v += d * d; }
-    const double vv = wol_block_sum(v, sm) / (double)n;
-    if (threadIdx.x == 0) {
-        if (mean) mean[blockIdx.x] = m;
-        if (var) var[blockIdx.x] = vv;
     }
 }
 

@@ -27,7 +27,10 @@
 #define WOL_FAST_CAPP 1024    // staged PAIRS per tile (cells are padded to an even count); with the tables
                               // this keeps a block under 53 KiB of LDS: three blocks (24 waves) per CU
 #endif
-#define WOL_FAST_TARGET ((WOL_FAST_BLOCK * 93) / 100)  // waters per tile aimed at (one lane each)
+#ifndef WOL_FAST_FILL
+#define WOL_FAST_FILL 97      // per cent of the lanes a tile may fill on average (a denser tile takes a second sweep)
+#endif
+#define WOL_FAST_TARGET ((WOL_FAST_BLOCK * WOL_FAST_FILL) / 100)  // waters per tile aimed at (one lane each)
 #define WOL_FAST_PADP 40      // head-room (pairs) incl. the dummy pair
 #ifndef WOL_FAST_MAXROWS
 #define WOL_FAST_MAXROWS 96   // (sz+2)*(ry+2) <= 96
@@ -158,7 +161,7 @@ __device__ __forceinline__ double wol_q_from_cosines(const double a[3], const do
 // finish for four real neighbours without the angle outputs
 __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const Top4& t, const double N0[3],
                                                        const double N1[3], const double N2[3], const double N3[3],
-                                                       const Box3& b, const QOut& o, int64_t slot,
+                                                       const Box3& b, const QOut& o, int64_t slot, int f,
                                                        int* __restrict__ lds_qh, int* __restrict__ lds_dh) {
     double P0[3], P1[3], P2[3], P3[3];
     wol_neighbour_point(a, N0[0], N0[1], N0[2], b, P0);
@@ -168,6 +171,7 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
     const double q = wol_q_from_cosines(a, P0, P1, P2, P3);
     if (o.q) o.q[slot] = q;
     if (o.q32) o.q32[slot] = (float)q;
+    wol_stat_add_lane(o, f, q);
     if (o.nn_idx) {
         int4 v; v.x = t.j0; v.y = t.j1; v.z = t.j2; v.w = t.j3;
         reinterpret_cast<int4*>(o.nn_idx)[slot] = v;
@@ -462,15 +466,20 @@ k_finish_fast(FastArgs a) {
     const int fstep = aff ? 8 : 1;
     const int kb = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int KB = aff ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-    for (int f = aff ? (int)(blockIdx.x & 7) : 0; f < a.F; f += fstep)
-    for (int s = kb * WOL_BLOCK + threadIdx.x; s < a.n; s += KB * WOL_BLOCK) {
+    __shared__ unsigned long long blk_stat[4];
+    for (int f = aff ? (int)(blockIdx.x & 7) : 0; f < a.F; f += fstep) {
+    long long sum_h = 0, sum_l = 0, sum_h2 = 0, sum_l2 = 0;  // this lane's share of frame f's sums of q, q^2
+    for (int s0 = kb * WOL_BLOCK; s0 < a.n; s0 += KB * WOL_BLOCK) {  // uniform bounds: whole waves stay in the loop
+        const int s = min(s0 + (int)threadIdx.x, a.n - 1);
+        const bool live = s0 + (int)threadIdx.x < a.n;
         const int64_t w = (int64_t)f * a.n + s;
         const FrameGrid& g = a.grids[f];
         if (g.maxshell < 0) continue;  // all-pairs frame
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
-        const int kd3 = a.prop_key[w];
-        bool slow = kd3 < 0;
-        if constexpr (LEAN) { if (!slow) {
+        const int kd3 = live ? a.prop_key[w] : 0;
+        bool slow = live && kd3 < 0;
+        long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
+        if constexpr (LEAN) { if (live && !slow) {
             // ---- lean path (trajectory mode: q, histograms, no per-neighbour outputs): the four
             //      proposed neighbours are certified and q is formed from their min-image vectors in
             //      proposal order -- no ranking, no second re-image, shared norms ----
@@ -540,9 +549,13 @@ k_finish_fast(FastArgs a) {
 #pragma unroll
                 for (int m = 0; m < 6; ++m) ssum += tm[m];
                 const double q = 1.0 - (3.0 / 8.0) * ssum;
-                const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
-                if (a.out.q) a.out.q[orow] = q;
-                if (a.out.q32) a.out.q32[orow] = (float)q;
+                if (a.out.q || a.out.q32) {
+                    const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
+                    if (a.out.q) a.out.q[orow] = q;
+                    if (a.out.q32) a.out.q32[orow] = (float)q;
+                }
+                wol_fix_split(q, &acc_h, &acc_l);
+                wol_fix_split(q * q, &acc_h2, &acc_l2);
                 if (lds_qh) {
                     const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
                     if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
@@ -559,7 +572,7 @@ k_finish_fast(FastArgs a) {
                     }
                 }
             }
-        } } else if (!slow) {
+        } } else if (live && !slow) {
             const int4 pr = a.prop[w];
             const double4 mev = sp[s];
             const double c[3] = {mev.x, mev.y, mev.z};
@@ -604,14 +617,37 @@ k_finish_fast(FastArgs a) {
                     N[k][0] = m.x; N[k][1] = m.y; N[k][2] = m.z;
                 }
                 const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
-                if (a.fast_q) wol_finish_water_fastq(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, lds_qh, lds_dh);
-                else wol_finish_water(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, lds_qh, lds_dh);
+                if (a.fast_q) wol_finish_water_fastq(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, f, lds_qh, lds_dh);
+                else wol_finish_water(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, f, lds_qh, lds_dh);
             }
         }
         if (slow) {
             const int pos = atomicAdd(a.slow_count, 1);
             a.slow_list[pos] = ((unsigned long long)f << 32) | (unsigned)s;
         }
+        sum_h += acc_h; sum_l += acc_l; sum_h2 += acc_h2; sum_l2 += acc_l2;
+    }
+    if constexpr (LEAN) {
+        if (a.out.stat) {
+            // frame f is done for this block: butterfly-sum the four integers over each wave, combine
+            // the waves in LDS, one thread adds the block's share to the frame's accumulators
+            if (threadIdx.x < 4) blk_stat[threadIdx.x] = 0ull;
+            __syncthreads();
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                sum_h += __shfl_xor(sum_h, off, 64); sum_l += __shfl_xor(sum_l, off, 64);
+                sum_h2 += __shfl_xor(sum_h2, off, 64); sum_l2 += __shfl_xor(sum_l2, off, 64);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&blk_stat[0], (unsigned long long)sum_h); atomicAdd(&blk_stat[1], (unsigned long long)sum_l);
+                atomicAdd(&blk_stat[2], (unsigned long long)sum_h2); atomicAdd(&blk_stat[3], (unsigned long long)sum_l2);
+            }
+            __syncthreads();
+            if (threadIdx.x < 4 && blk_stat[threadIdx.x] != 0ull)
+                atomicAdd(&a.out.stat[4 * (size_t)f + threadIdx.x], blk_stat[threadIdx.x]);
+            __syncthreads();
+        }
+    }
     }
     __syncthreads();
     if (lds_qh) wol_hist_flush(lds_qh, a.out.qbins, a.out.qhist);
@@ -716,7 +752,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
             const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
             const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
             wol_finish_water(c, all, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + (int)__double_as_longlong(v.w),
-                             lds_qh, lds_dh);
+                             f, lds_qh, lds_dh);
         }
     }
     __syncthreads();
