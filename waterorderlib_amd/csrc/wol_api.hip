@@ -86,7 +86,7 @@ struct wol_ctx {
     bool time_kernels = false;
     bool lds_sort = true;
     // workspace
-    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, stat, slow_list, slow_count, prop, prop_key, stamps;
+    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -329,7 +329,25 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         for (int f = 0; f < F; ++f) ncell_max = std::max(ncell_max, gh[f].ncell);
         const size_t sort_lds = sizeof(int) * ((size_t)ncell_max + 1);
         const bool lds_sort = F >= 128 && sort_lds + sizeof(int) * WOL_SORT_BLOCK + 1024 <= 160 * 1024 && c->lds_sort;
-        if (lds_sort) {
+        bool layer_sort = c->lds_sort && F >= 64;
+        int nz_max = 0, nrow_max = 0;
+        for (int f = 0; f < F && layer_sort; ++f) {
+            if (gh[f].maxshell < 0) { layer_sort = false; break; }
+            if (gh[f].nc[0] > WOL_L2_MAXNX || gh[f].nc[1] * gh[f].nc[2] > WOL_L1_MAXROWS) layer_sort = false;
+            nz_max = std::max(nz_max, gh[f].nc[2]);
+            nrow_max = std::max(nrow_max, gh[f].nc[1] * gh[f].nc[2]);
+        }
+        if (layer_sort) {
+            // streaming two-level sort: (z, y) row buckets, then a counting sort inside every row
+            const int ro_stride = nrow_max + 1;
+            WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
+            WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
+            hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), 0, c->stream, fv,
+                               c->grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>());
+            hipLaunchKernelGGL(k_sort_in_row, dim3(nz_max, F), dim3(WOL_BLOCK), 0, c->stream, c->grids.as<FrameGrid>(),
+                               c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, c->cells.as<int>(),
+                               c->sorted.as<double4>(), s32);
+        } else if (lds_sort) {
             if (sort_lds > c->sort_lds_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_frame_lds<T>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(int) * WOL_SORT_BLOCK - 1024)));
@@ -635,7 +653,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->sorted, &c->sorted32, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);

@@ -211,6 +211,148 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming two-level sort for large batches.  A random-order frame makes a direct scatter into
+// the cell-sorted arrays a storm of partial-line HBM writes; here every global access is a stream:
+//   level 1 (one block per frame): histogram of the (z, y) cell rows in LDS, then every water is
+//           appended to its row's bucket in tmp[] -- ~1000 write streams whose open lines stay in L2;
+//   level 2 (one wave per row): the bucket (~100 waters, second read served by L1) is counting-sorted
+//           by cx with per-wave LDS counters straight into the final arrays; consecutive rows are
+//           consecutive in the output, so those writes stream too.
+// ---------------------------------------------------------------------------------------------
+#define WOL_L1_MAXROWS 4096   // nz * ny rows counted in LDS by level 1
+#define WOL_L2_MAXNX 128      // cells of a row handled by one wave of level 2
+template <typename T>
+__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
+            double4* __restrict__ tmp) {
+    __shared__ int cnt[WOL_L1_MAXROWS + 1];
+    __shared__ int part[WOL_SORT_BLOCK];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameGrid& g = grids[f];
+    const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
+    const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
+    for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) cnt[c] = 0;
+    __syncthreads();
+    constexpr int U = 8;
+    for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
+        double y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < fv.n) { const T* p = base + (int64_t)i * fv.atom_stride; y[u] = (double)p[1]; z[u] = (double)p[2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * WOL_SORT_BLOCK < fv.n)
+                atomicAdd(&cnt[wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the row counters in place
+    const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
+    const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
+    int s = 0;
+    for (int k = sb; k < se; ++k) s += cnt[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int* ro = row_off + (int64_t)f * ro_stride;
+    int run = part[tid] - s;
+    for (int k = sb; k < se; ++k) { const int v = cnt[k]; cnt[k] = run; ro[k] = run; run += v; }
+    if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
+    __syncthreads();
+    double4* __restrict__ out = tmp + (int64_t)f * fv.n;
+    for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
+        double x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < fv.n) {
+                const T* p = base + (int64_t)i * fv.atom_stride;
+                x[u] = (double)p[0]; y[u] = (double)p[1]; z[u] = (double)p[2];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < fv.n) {
+                const int row = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
+                const int pos = atomicAdd(&cnt[row], 1);
+                double4 v;
+                v.x = x[u]; v.y = y[u]; v.z = z[u];
+                v.w = __longlong_as_double((long long)i);
+                out[pos] = v;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
+              const double4* __restrict__ tmp, int n, int* __restrict__ cell_start,
+              double4* __restrict__ sorted, float4* __restrict__ sorted32) {
+    __shared__ int cnt_all[(WOL_BLOCK / 64) * WOL_L2_MAXNX];
+    const int f = blockIdx.y, cz = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const FrameGrid& g = grids[f];
+    const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
+    if (cz >= nz) return;
+    int* cnt = cnt_all + wave * WOL_L2_MAXNX;
+    const int* ro = row_off + (int64_t)f * ro_stride;
+    const double4* __restrict__ in = tmp + (int64_t)f * n;
+    double4* __restrict__ so = sorted + (int64_t)f * n;
+    float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
+    for (int cy = wave; cy < ny; cy += WOL_BLOCK / 64) {  // one wave per row, no block-level barriers
+        const int row = cz * ny + cy;
+        const int b = ro[row], e = ro[row + 1];
+        for (int c = lane; c < nx; c += 64) cnt[c] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = b + lane; i < e; i += 64)
+            atomicAdd(&cnt[wol_cell_coord(in[i].x, g.box.ib[0], nx, nullptr)], 1);
+        __builtin_amdgcn_wave_barrier();
+        // exclusive scan over the row's cells (nx <= 128: two per lane), cell_start of the row
+        {
+            const int c0 = 2 * lane, c1 = 2 * lane + 1;
+            const int v0 = c0 < nx ? cnt[c0] : 0, v1 = c1 < nx ? cnt[c1] : 0;
+            int inc = v0 + v1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
+            }
+            const int ex = b + inc - (v0 + v1);
+            int* __restrict__ cs = cell_start + g.cell_base + (int64_t)row * nx;
+            if (c0 < nx) { cnt[c0] = ex; cs[c0] = ex; }
+            if (c1 < nx) { cnt[c1] = ex + v0; cs[c1] = ex + v0; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = b + lane; i < e; i += 64) {  // second read: the row bucket is a few KB, L1-hot
+            const double4 v = in[i];
+            double ux = v.x * g.box.ib[0]; ux -= floor(ux);
+            double uy = v.y * g.box.ib[1]; uy -= floor(uy);
+            double uz = v.z * g.box.ib[2]; uz -= floor(uz);
+            int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);  // as wol_cell_coord
+            const int dst = atomicAdd(&cnt[cx], 1);
+            so[dst] = v;
+            if (so32) {
+                float4 w;
+                w.x = (float)((ux * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
+                w.y = (float)((uy * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
+                w.z = (float)((uz * (double)nz - (double)cz) * g.cw[2] * (double)g.scale);
+                w.w = 0.f;
+                so32[dst] = w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (cz == nz - 1 && threadIdx.x == 0) cell_start[g.cell_base + (int64_t)nz * ny * nx] = n;
+}
+
 // =============================================================================================
 // epilogue shared by the search kernels
 // =============================================================================================
