@@ -157,6 +157,7 @@ def main():
         elapsed = float(t.item())
     k_ms, k_launches = ctx.kernel_time(reset=False)
     slow_last = ctx.counter("slow_waters")
+    dens_level = ctx.counter("density_level")
 
     if rank == 0:
         traffic = args.traffic_bytes
@@ -194,6 +195,7 @@ def main():
                          "traffic": traffic,
                          "launches": int(k_launches), "avg_launch_ms": k_avg_s * 1e3,
                          "exact_path_fraction_last_launch": slow_last / float(F * n),
+                         "tile_density_level": dens_level,
                          "alg_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline:

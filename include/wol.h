@@ -63,7 +63,8 @@ int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int reset);
 
 /* diagnostic counters of the LAST q call on this context (synchronises the stream):
- * "slow_waters" = waters the fp32 filter could not certify and the exact search finished */
+ * "slow_waters" = waters the fp32 filter could not certify and the exact search finished;
+ * "density_level" = tile-shape level the device picked for frame 0 (0 = box-average density) */
 int wol_ctx_get_counter(wol_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- level 1: the f2py `waterlib` routines on the path (host pointers) -------------------- */

@@ -86,7 +86,7 @@ struct wol_ctx {
     bool time_kernels = false;
     bool lds_sort = true;
     // workspace
-    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
+    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, level, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -109,7 +109,23 @@ Box3 make_box(const double* box) {
 
 // Builds the uniform grid of one frame.  Returns false when the frame must take the all-pairs
 // path: a non-periodic axis (BoxL < 0), BoxL == 0 or a non-finite length.
+bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g);
+
+// trajectories at constant volume repeat one box: keep the last grid
 bool make_grid(const double* box, int n, double cell_width, double high, FrameGrid* g) {
+    static thread_local struct { double box[3], cw, high; int n; bool ok, valid = false; FrameGrid g; } last;
+    if (last.valid && last.n == n && last.cw == cell_width && last.high == high && last.box[0] == box[0] &&
+        last.box[1] == box[1] && last.box[2] == box[2]) {
+        *g = last.g;
+        return last.ok;
+    }
+    const bool ok = make_grid_uncached(box, n, cell_width, high, g);
+    last.box[0] = box[0]; last.box[1] = box[1]; last.box[2] = box[2];
+    last.cw = cell_width; last.high = high; last.n = n; last.ok = ok; last.g = *g; last.valid = true;
+    return ok;
+}
+
+bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g) {
     g->box = make_box(box);
     g->maxshell = -1;
     g->ncell = 1;
@@ -146,45 +162,57 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
 
     // ---- tiling for the filtered kernel (wol_search_fast.hip) ----
     g->fast_ok = 0;
-    g->sx = g->ry = g->sz = g->ntx = g->nty = g->ntz = 1;
+    g->nlev = 0;
     g->ntiles = 0;
     g->scale = 1.f; g->tmax = 0.f; g->S = 1.0; g->eps_units = 0;
     if (g->nc[0] >= 3 && g->nc[1] >= 3 && g->nc[2] >= 3) {
         const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
         const double wpc = std::fmax((double)n / (double)g->ncell, 0.05);
-        // tile = sx x ry x sz cells: as many waters as fit one sweep of the block (one lane per water,
-        // ~7 % head-room) while the halo'd tile ((sz+2) layers of (ry+2) x (sx+2) cells, each padded to an
-        // even count, +15 %) fits the LDS pair buffer and the row tables; among the fullest shapes the one
-        // with the smallest halo.  Tiles of a frame are equal-sized up to one cell per axis.
-        double best = -1.0;
-        g->sx = 1; g->ry = 1; g->sz = 1; g->ntx = g->nc[0]; g->nty = g->nc[1]; g->ntz = g->nc[2];
-        for (int ntx = 1; ntx <= g->nc[0]; ++ntx) {
-            const int sx = (g->nc[0] + ntx - 1) / ntx;
-            if (sx > WOL_FAST_MAXSX || (g->nc[0] + sx - 1) / sx != ntx) continue;
-            for (int nty = 1; nty <= g->nc[1]; ++nty) {
-                const int ry = (g->nc[1] + nty - 1) / nty;
-                if (ry > WOL_FAST_MAXRY || (g->nc[1] + ry - 1) / ry != nty) continue;
-                for (int ntz = 1; ntz <= g->nc[2]; ++ntz) {
-                    const int sz = (g->nc[2] + ntz - 1) / ntz;
-                    if (sz > WOL_FAST_MAXSZ || (g->nc[2] + sz - 1) / sz != ntz) continue;
-                    if (sz * ry > WOL_FAST_MAXQROWS || (sz + 2) * (ry + 2) > WOL_FAST_MAXROWS) continue;
-                    const double q = sx * ry * sz * wpc;
-                    const bool unit = (sx == 1 && ry == 1 && sz == 1);
-                    if (q > (double)WOL_FAST_TARGET && !unit) continue;
-                    const double staged = (double)(sz + 2) * (ry + 2) * (sx + 2) * (wpc + 0.5);
-                    if (staged * 1.15 > 2.0 * WOL_FAST_CAPP && !unit) continue;
-                    // fill of the block's lanes first (5 % bands), then the halo ratio
-                    const double band = std::floor(q / (0.05 * WOL_FAST_TARGET));
-                    const double score = band - staged / (q * 100.0);
-                    if (score > best) {
-                        best = score;
-                        g->sx = sx; g->ry = ry; g->sz = sz; g->ntx = ntx; g->nty = nty; g->ntz = ntz;
+        // Tile shapes for WOL_NLEV local densities (waters per cell), from the box average upwards; the
+        // device picks the level after the sort (k_pick_level).  A tile = sx x ry x sz cells: as many
+        // waters as fit one sweep of the block (one lane per water) while the halo'd tile ((sz+2) layers
+        // of (ry+2) x (sx+2) cells, each padded to an even count, +15 %) fits the LDS pair buffer and the
+        // row tables; among the fullest shapes the one with the smallest halo.
+        static const double lev_mult[WOL_NLEV] = {1.10, 1.35, 1.75, 2.4, 4.0, 8.0};  // densest tile-sized window / box average
+        g->nlev = WOL_NLEV;
+        int max_sx = 1, max_ry = 1, max_sz = 1;
+        for (int l = 0; l < WOL_NLEV; ++l) {
+            // a level is picked while the densest window stays below lev_wpc; its tiles are sized for the
+            // typical tile of such a frame (the densest windows of a homogeneous liquid sit ~10 % above
+            // the mean; a tile that does get more waters than lanes takes a second sweep)
+            g->lev_wpc[l] = (float)(wpc * lev_mult[l]);
+            const double w = wpc * lev_mult[l] / 1.10;
+            double best = -1.0;
+            int bsx = 1, bry = 1, bsz = 1, bntx = g->nc[0], bnty = g->nc[1], bntz = g->nc[2];
+            for (int sx0 = 1; sx0 <= std::min(g->nc[0], WOL_FAST_MAXSX); ++sx0) {
+                const int ntx = (g->nc[0] + sx0 - 1) / sx0, sx = (g->nc[0] + ntx - 1) / ntx;  // equalised
+                if (sx != sx0) continue;
+                for (int sz0 = 1; sz0 <= std::min(g->nc[2], WOL_FAST_MAXSZ); ++sz0) {
+                    const int ntz = (g->nc[2] + sz0 - 1) / sz0, sz = (g->nc[2] + ntz - 1) / ntz;
+                    if (sz != sz0) continue;
+                    for (int ry0 = 1; ry0 <= std::min(g->nc[1], WOL_FAST_MAXRY); ++ry0) {
+                        const int nty = (g->nc[1] + ry0 - 1) / ry0, ry = (g->nc[1] + nty - 1) / nty;
+                        if (ry != ry0) continue;
+                        if (sz * ry > WOL_FAST_MAXQROWS || (sz + 2) * (ry + 2) > WOL_FAST_MAXROWS) continue;
+                        const double q = sx * ry * sz * w;
+                        const bool unit = (sx == 1 && ry == 1 && sz == 1);
+                        if (q > (double)WOL_FAST_TARGET && !unit) continue;
+                        const double staged = (double)(sz + 2) * (ry + 2) * (sx + 2) * (w + 0.5);
+                        if (staged * 1.15 > 2.0 * WOL_FAST_CAPP && !unit) continue;
+                        // fill of the block's lanes first (5 % bands), then the halo ratio
+                        const double band = std::floor(q / (0.05 * WOL_FAST_TARGET));
+                        const double score = band - staged / (q * 100.0);
+                        if (score > best) { best = score; bsx = sx; bry = ry; bsz = sz; bntx = ntx; bnty = nty; bntz = ntz; }
                     }
                 }
             }
+            g->lev_sx[l] = (short)bsx; g->lev_ry[l] = (short)bry; g->lev_sz[l] = (short)bsz;
+            g->lev_ntx[l] = (short)bntx; g->lev_nty[l] = (short)bnty; g->lev_ntz[l] = (short)bntz;
+            g->lev_ntiles[l] = bntx * bnty * bntz;
+            g->ntiles = std::max(g->ntiles, g->lev_ntiles[l]);
+            max_sx = std::max(max_sx, bsx); max_ry = std::max(max_ry, bry); max_sz = std::max(max_sz, bsz);
         }
-        g->ntiles = g->ntx * g->nty * g->ntz;
         const double kunits = std::ldexp(1.0, 32 - WOL_ID_BITS);
         g->S = kunits / (rmax * rmax);                      // key units over [0, rmax^2)
         g->scale = (float)std::sqrt(g->S);
@@ -194,7 +222,7 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
         // magnitude M), differences of two such numbers are exact, the three fmas round to integers
         // (staged coordinates are cell-local values plus a cell offset, centred on the tile: M is half
         // the halo'd tile extent)
-        const double ext = std::fmax(0.5 * (g->sx + 2) * g->cw[0], std::fmax(0.5 * (g->ry + 2) * g->cw[1], 0.5 * (g->sz + 2) * g->cw[2]))
+        const double ext = std::fmax(0.5 * (max_sx + 2) * g->cw[0], std::fmax(0.5 * (max_ry + 2) * g->cw[1], 0.5 * (max_sz + 2) * g->cw[2]))
                            + std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double M = ext * g->scale;
         const double ulpM = std::ldexp(1.0, (int)std::ceil(std::log2(M)) - 24);
@@ -390,7 +418,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             WOL_TRY(c->prop.ensure(sizeof(int4) * (size_t)F * n));
             WOL_TRY(c->prop_key.ensure(sizeof(int) * (size_t)F * n));
             HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+            WOL_TRY(c->level.ensure(sizeof(int) * (size_t)F));
+            hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->stream, a.grids, a.cell_start, c->level.as<int>());
             FastArgs fa;
+            fa.level = c->level.as<int>();
             fa.grids = a.grids; fa.sorted = a.sorted; fa.sorted32 = s32; fa.cell_start = a.cell_start;
             fa.n = n; fa.F = F; fa.highsq = highsq; fa.high = high; fa.out = out;
             fa.tiles_per_frame = tiles_max;
@@ -653,7 +684,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->sorted, &c->sorted32, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->level, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
@@ -717,6 +748,16 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
             int v = 0;
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(&v, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost));
+            *value = v;
+        }
+        return WOL_OK;
+    }
+    if (std::string(key) == "density_level") {  // tile-shape level of frame 0 of the last batch
+        *value = -1;
+        if (c->level.p) {
+            int v = 0;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(&v, c->level.p, sizeof(int), hipMemcpyDeviceToHost));
             *value = v;
         }
         return WOL_OK;

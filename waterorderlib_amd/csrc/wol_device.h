@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #define WOL_PI 3.1415926535897931
+#define WOL_NLEV 6
 
 struct Box3 {
     double L[3];   // BoxL
@@ -26,9 +27,15 @@ struct FrameGrid {
     int64_t cell_base;  // offset of this frame's cell_start[] in the batch array
     // ---- tiling of the filtered (fp32 + exact finish) search kernel ----
     int fast_ok;        // grid has >= 3 cells per axis and the cutoff covers the guaranteed radius
-    int sx, ry, sz;     // tile = sx cells along x by ry rows along y by sz layers along z
-    int ntx, nty, ntz;  // tiles per axis
-    int ntiles;
+    // tile = sx cells along x by ry rows along y by sz layers along z.  The shape is chosen on the
+    // device, after the sort, from a short list the host prepared for increasing local densities
+    // (waters per cell): level l fits tiles as long as the densest cell row holds <= lev_wpc[l] per cell.
+    int nlev;
+    float lev_wpc[WOL_NLEV];
+    short lev_sx[WOL_NLEV], lev_ry[WOL_NLEV], lev_sz[WOL_NLEV];
+    short lev_ntx[WOL_NLEV], lev_nty[WOL_NLEV], lev_ntz[WOL_NLEV];
+    int lev_ntiles[WOL_NLEV];
+    int ntiles;         // max over the levels (launch bound)
     float scale;        // sqrt(S): staged coordinates are multiplied by it so d^2 comes out in key units
     float tmax;         // 2^23 + 2^21 - 1: saturation of the biased squared distance
     double S;           // key units per A^2 (2^21 / r2max)

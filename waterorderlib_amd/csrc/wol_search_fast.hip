@@ -71,6 +71,7 @@ struct FastArgs {
     unsigned long long* slow_list;  // (frame << 32 | sorted slot) of waters left to the exact kernel
     int* slow_count;
     int fast_q;             // 1: q straight from the cosines (no acos/deg/cos round trip); needs out.ang == null
+    const int* level;       // [F] density level picked by k_pick_level (index into FrameGrid::lev_*)
     int4* prop;             // [F][n] by sorted slot: sorted slots of the four proposed neighbours
     int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
     unsigned long long* stamps;  // diagnostic builds only
@@ -194,6 +195,52 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// kernel 0: density level of every frame.  The fullest 4-row x 2-layer window of cell rows gives the
+// local waters-per-cell the tiles have to cope with (a slab with vacuum, a droplet: far above the box
+// average); the first prepared tile shape that fits it is selected.  One block per frame.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start, int* __restrict__ level) {
+    __shared__ int rows[12288];
+    __shared__ int smax[WOL_BLOCK];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameGrid& g = grids[f];
+    const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
+    const int* __restrict__ cs = cell_start + g.cell_base;
+    const bool ok = g.maxshell >= 0 && nrow <= 12288;
+    if (ok)
+        for (int r = tid; r < nrow; r += WOL_BLOCK) rows[r] = cs[(r + 1) * nx] - cs[r * nx];
+    __syncthreads();
+    // densest window of 4 rows x 2 layers (about the size of a tile; a single row is too noisy)
+    int m = 0;
+    const int wy = min(4, ny), wz = min(2, nz);
+    if (ok)
+        for (int r = tid; r < nrow; r += WOL_BLOCK) {
+            const int cz = r / ny, cy = r - cz * ny;
+            int sum = 0;
+            for (int dz = 0; dz < wz; ++dz)
+                for (int dy = 0; dy < wy; ++dy)
+                    sum += rows[wol_wrap_cell(cz + dz, nz) * ny + wol_wrap_cell(cy + dy, ny)];
+            m = max(m, sum);
+        }
+    smax[tid] = m;
+    __syncthreads();
+    for (int off = WOL_BLOCK >> 1; off > 0; off >>= 1) {
+        if (tid < off) smax[tid] = max(smax[tid], smax[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int lev = g.nlev - 1;
+        if (ok) {
+            const float wpc = (float)smax[0] / (float)(nx * wy * wz);
+            for (int l = g.nlev - 1; l >= 0; --l)
+                if (wpc <= g.lev_wpc[l]) lev = l;
+        }
+        level[f] = lev;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernel 1: proposal.  Small register footprint (no fp64), occupancy limited by LDS only.
 // Writes per water (indexed by its slot in the sorted array) the sorted slots of the four proposed
 // neighbours and the 4th key (or -1 when the proposal cannot be certified by keys alone).
@@ -224,21 +271,30 @@ k_search_fast(FastArgs a) {
     int f = aff ? (int)(blockIdx.x & 7) : 0;
     int tile = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
+    // tiles of frame f at the level the device picked for it (0 for frames this kernel skips)
+    auto tiles_of = [&](int ff) -> int {
+        if (ff >= a.F) return 0;
+        const FrameGrid& gg = a.grids[ff];
+        return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.lev_ntiles[a.level[ff]];
+    };
+    int nt_f = tiles_of(f);
     for (;; tile += tstep) {
-        while (tile >= a.tiles_per_frame) { tile -= a.tiles_per_frame; f += fstep; }
+        while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
         if (f >= a.F) break;
         const FrameGrid& g = a.grids[f];
-        if (tile >= g.ntiles || g.maxshell < 0 || !g.fast_ok) continue;  // uniform over the block
+        const int lev = a.level[f];
         const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
+        const int gsx = g.lev_sx[lev], gry = g.lev_ry[lev], gsz = g.lev_sz[lev];
+        const int gntx = g.lev_ntx[lev], gnty = g.lev_nty[lev];
         // tile -> (tx, ty, tz) through float reciprocals (exact for these small operands)
-        const int ntxy = g.ntx * g.nty;
+        const int ntxy = gntx * gnty;
         const int tz = (int)(((float)tile + 0.5f) / (float)ntxy);
         const int trem = tile - tz * ntxy;
-        const int ty = (int)(((float)trem + 0.5f) / (float)g.ntx);
-        const int tx = trem - ty * g.ntx;
-        const int x0 = tx * g.sx, sxe = min(g.sx, nx - x0);
-        const int y0 = ty * g.ry, re = min(g.ry, ny - y0);
-        const int z0 = tz * g.sz, sze = min(g.sz, nz - z0);
+        const int ty = (int)(((float)trem + 0.5f) / (float)gntx);
+        const int tx = trem - ty * gntx;
+        const int x0 = tx * gsx, sxe = min(gsx, nx - x0);
+        const int y0 = ty * gry, re = min(gry, ny - y0);
+        const int z0 = tz * gsz, sze = min(gsz, nz - z0);
         const int rpl = re + 2;           // staged rows per z layer
         const int nrows = (sze + 2) * rpl, ncr = sxe + 2;
         const int nqr = sze * re;         // rows holding the tile's own waters
@@ -450,8 +506,11 @@ k_search_fast(FastArgs a) {
 // 4th distance is inside the radius the 27-cell stencil guarantees (and agrees with the fp32 key),
 // computes angles / q / histograms; everything else goes to the exact list.
 // ---------------------------------------------------------------------------------------------
+#ifndef WOL_FINISH_WPS
+#define WOL_FINISH_WPS 4
+#endif
 template <bool LEAN>
-__global__ void __launch_bounds__(WOL_BLOCK)
+__global__ void __launch_bounds__(WOL_BLOCK, WOL_FINISH_WPS)
 k_finish_fast(FastArgs a) {
     extern __shared__ int lds_hist[];
     int* lds_qh = a.out.qhist ? lds_hist : nullptr;
