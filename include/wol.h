@@ -56,7 +56,10 @@ int wol_ctx_set_stream(wol_ctx* ctx, void* hip_stream);
 int wol_ctx_synchronize(wol_ctx* ctx);
 /* tunables: "cell_width" (A, default 4.5), "frames_per_batch", "path" (0 auto, 1 force brute-force,
  * 2 force exact cell kernel, 3 force filtered cell kernel), "lds_sort" (1 = per-frame counting sort
- * in LDS when it fits, 0 = global-atomic form), "time_kernels" (0/1) */
+ * in LDS when it fits, 0 = global-atomic form), "overlap" (1 = sort the next batch on a second stream beside
+ * the current batch's search; default 0: measured no gain), "inputs_resident" (1 = the caller guarantees that device input buffers are
+ * complete in memory when a call is made, not merely enqueued earlier on the stream, so the sort of one call
+ * may overlap the previous call's kernels; default 0), "time_kernels" (0/1) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */

@@ -274,3 +274,22 @@ def test_drivers(oracle, tmp_path, monkeypatch):
     l0 = [oracle.getLSI(O[t], O[t], boxes[t])[0] for t in range(5)]
     assert abs(avgL[0][0] - np.mean([np.mean(x) for x in l0])) < 1e-13
     assert np.loadtxt("lsiDistribution_0.txt").shape == (500, 2)
+
+
+def test_two_stream_overlap_option_gives_identical_results():
+    """opt-in: the sort of a batch on a second stream beside the previous batch's kernels"""
+    import torch
+    from waterorderlib_amd import engine, synth, _lib
+    xyz, boxes = synth.water_frames(1500, 192, seed=81)
+    fr = torch.from_numpy(xyz).cuda()
+    a = engine.tet_order_traj(fr, boxes, want_q=True)
+    ctx = _lib.Context(0)
+    ctx.set_option("overlap", 1)
+    ctx.set_option("inputs_resident", 1)
+    ctx.set_option("frames_per_batch", 64)
+    outs = [engine.tet_order_traj(fr, boxes, want_q=True, ctx=ctx) for _ in range(3)]
+    torch.cuda.synchronize()
+    for b in outs:
+        assert torch.equal(a.q, b.q) and torch.equal(a.qhist, b.qhist) and torch.equal(a.dhist, b.dhist)
+        assert torch.equal(a.mean, b.mean) and torch.equal(a.var, b.var)
+    ctx.close()

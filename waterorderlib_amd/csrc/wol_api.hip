@@ -86,7 +86,23 @@ struct wol_ctx {
     bool time_kernels = false;
     bool lds_sort = true;
     // workspace
-    DevBuf sorted, sorted32, cellid, rank, cells, grids, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, level, slow_list, slow_count, prop, prop_key, stamps;
+    // cell-sorted data is double-buffered: the sort of the next batch runs on `sort_stream` beside the
+    // search / finish kernels of the current batch on `stream` (the sort is memory-bound, the search
+    // VALU-bound); events hand the sets back and forth
+    struct SortSet {
+        DevBuf sorted, sorted32, cells, grids, level;
+        hipEvent_t sorted_ev = nullptr;  // recorded on the sort stream when the set is filled
+        hipEvent_t free_ev = nullptr;    // recorded on `stream` when its last reader is done
+        bool used = false;
+    } sets[2];
+    int next_set = 0;
+    hipStream_t sort_stream = nullptr;
+    hipEvent_t in_ev = nullptr;
+    bool overlap = false;  // measured on MI355X: the sort and the search contend for the same CU slots and
+                           // memory latency, running them side by side gains nothing; kept as an opt-in
+    bool inputs_resident = false;
+    SortSet* last_set = nullptr;
+    DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -295,7 +311,7 @@ struct HistArgs {
 // out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
 template <typename T>
 int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
-                int64_t sub_stride, int ns, double low, double high, QOut out) {
+                int64_t sub_stride, int ns, double low, double high, QOut out, bool allow_pipe = false) {
     const int n = fv.n;
     if (F <= 0 || ns <= 0) return WOL_OK;
     const double lowsq = low * low, highsq = high * high;
@@ -328,14 +344,35 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     }
 
     if (n_cell_frames > 0) {
-        WOL_TRY(c->grids.ensure(sizeof(FrameGrid) * (size_t)F));
-        WOL_TRY(c->cells.ensure(sizeof(int) * (size_t)cell_total));
-        WOL_TRY(c->sorted.ensure(sizeof(double4) * (size_t)F * n));
+        wol_ctx::SortSet& S = c->sets[c->next_set];
+        c->next_set ^= 1;
+        // the sort goes to the second stream when this is a large device-resident batch (the trajectory
+        // path): it then overlaps the previous batch's search / finish kernels on the main stream
+        const bool pipe = c->overlap && allow_pipe && F >= 64;
+        if (!S.sorted_ev) {
+            HIP_TRY(hipEventCreateWithFlags(&S.sorted_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.free_ev, hipEventDisableTiming));
+        }
+        hipStream_t ss = c->stream;
+        if (pipe) {
+            if (!c->sort_stream) HIP_TRY(hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking));
+            if (!c->in_ev) HIP_TRY(hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
+            ss = c->sort_stream;
+            if (!c->inputs_resident) {
+                // the frames may be the product of work the caller enqueued earlier on its stream
+                HIP_TRY(hipEventRecord(c->in_ev, c->stream));
+                HIP_TRY(hipStreamWaitEvent(ss, c->in_ev, 0));
+            }
+            if (S.used) HIP_TRY(hipStreamWaitEvent(ss, S.free_ev, 0));  // last readers of this set are done
+        }
+        WOL_TRY(S.grids.ensure(sizeof(FrameGrid) * (size_t)F));
+        WOL_TRY(S.cells.ensure(sizeof(int) * (size_t)cell_total));
+        WOL_TRY(S.sorted.ensure(sizeof(double4) * (size_t)F * n));
         WOL_TRY(c->cellid.ensure(sizeof(int) * (size_t)F * n));
         WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * n));
-        HIP_TRY(hipMemcpyAsync(c->grids.p, gh, sizeof(FrameGrid) * (size_t)F, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(S.grids.p, gh, sizeof(FrameGrid) * (size_t)F, hipMemcpyHostToDevice, ss));
         if (!c->grid_ev) HIP_TRY(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
+        HIP_TRY(hipEventRecord(c->grid_ev, ss));
         c->grid_copy_pending = true;
         bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
         int tiles_max = 0;
@@ -347,8 +384,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         if (tiles_max == 0) use_fast = false;
         float4* s32 = nullptr;
         if (use_fast) {
-            WOL_TRY(c->sorted32.ensure(sizeof(float4) * (size_t)F * n));
-            s32 = c->sorted32.as<float4>();
+            WOL_TRY(S.sorted32.ensure(sizeof(float4) * (size_t)F * n));
+            s32 = S.sorted32.as<float4>();
         }
         // sort: one block per frame with the cell counters in LDS when the batch can fill the chip that
         // way (a block moves ~24 GB/s, one CU's share, so it needs >= ~128 frames to beat the global-
@@ -370,34 +407,40 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             const int ro_stride = nrow_max + 1;
             WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
             WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
-            hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), 0, c->stream, fv,
-                               c->grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>());
-            hipLaunchKernelGGL(k_sort_in_row, dim3(nz_max, F), dim3(WOL_BLOCK), 0, c->stream, c->grids.as<FrameGrid>(),
-                               c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, c->cells.as<int>(),
-                               c->sorted.as<double4>(), s32);
+            hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), 0, ss, fv,
+                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>());
+            hipLaunchKernelGGL(k_sort_in_row, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
+                               c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
+                               S.sorted.as<double4>(), s32);
         } else if (lds_sort) {
             if (sort_lds > c->sort_lds_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_frame_lds<T>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - sizeof(int) * WOL_SORT_BLOCK - 1024)));
                 c->sort_lds_set = 160 * 1024;
             }
-            hipLaunchKernelGGL(k_sort_frame_lds<T>, dim3(F), dim3(WOL_SORT_BLOCK), sort_lds, c->stream, fv,
-                               c->grids.as<FrameGrid>(), c->cells.as<int>(), c->rank.as<int>(),
-                               c->sorted.as<double4>(), s32);
+            hipLaunchKernelGGL(k_sort_frame_lds<T>, dim3(F), dim3(WOL_SORT_BLOCK), sort_lds, ss, fv,
+                               S.grids.as<FrameGrid>(), S.cells.as<int>(), c->rank.as<int>(),
+                               S.sorted.as<double4>(), s32);
         } else {
-            HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)cell_total, c->stream));
+            HIP_TRY(hipMemsetAsync(S.cells.p, 0, sizeof(int) * (size_t)cell_total, ss));
             const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
-            hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                               c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
-            hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
-            hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                               c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>(), s32);
+            hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, ss, fv, S.grids.as<FrameGrid>(),
+                               S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
+            hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, ss, S.grids.as<FrameGrid>(), S.cells.as<int>());
+            hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, ss, fv, S.grids.as<FrameGrid>(),
+                               S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), S.sorted.as<double4>(), s32);
         }
 
+        if (pipe) {
+            HIP_TRY(hipEventRecord(S.sorted_ev, ss));
+            HIP_TRY(hipStreamWaitEvent(c->stream, S.sorted_ev, 0));
+        }
+        c->last_set = &S;
+
         SearchArgs a;
-        a.grids = c->grids.as<FrameGrid>();
-        a.sorted = c->sorted.as<double4>();
-        a.cell_start = c->cells.as<int>();
+        a.grids = S.grids.as<FrameGrid>();
+        a.sorted = S.sorted.as<double4>();
+        a.cell_start = S.cells.as<int>();
         a.n = n;
         a.F = F;
         a.sub = reinterpret_cast<const double*>(sub);  // only double reaches here with sub != null
@@ -418,10 +461,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             WOL_TRY(c->prop.ensure(sizeof(int4) * (size_t)F * n));
             WOL_TRY(c->prop_key.ensure(sizeof(int) * (size_t)F * n));
             HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
-            WOL_TRY(c->level.ensure(sizeof(int) * (size_t)F));
-            hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->stream, a.grids, a.cell_start, c->level.as<int>());
+            WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
+            hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->stream, a.grids, a.cell_start, S.level.as<int>());
             FastArgs fa;
-            fa.level = c->level.as<int>();
+            fa.level = S.level.as<int>();
             fa.grids = a.grids; fa.sorted = a.sorted; fa.sorted32 = s32; fa.cell_start = a.cell_start;
             fa.n = n; fa.F = F; fa.highsq = highsq; fa.high = high; fa.out = out;
             fa.tiles_per_frame = tiles_max;
@@ -460,6 +503,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             hipLaunchKernelGGL(k_search_exact, dim3(grid), dim3(WOL_BLOCK), hist_lds, c->stream, a);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
         }
+        HIP_TRY(hipEventRecord(S.free_ev, c->stream));
+        S.used = true;
     }
     for (int f : brute_frames) {
         PointsView<T> pv{fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, n};
@@ -483,6 +528,8 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
         HIP_TRY(hipEventSynchronize(c->grid_ev));
         c->grid_copy_pending = false;
     }
+    wol_ctx::SortSet& S = c->sets[0];
+    if (c->sort_stream) HIP_TRY(hipStreamSynchronize(c->sort_stream));  // rare path: keep it simple
     WOL_TRY(c->grids_host.ensure(sizeof(FrameGrid)));
     FrameGrid* gh = c->grids_host.as<FrameGrid>();
     const bool ok = make_grid(box, n, std::fmax(reach * 0.5, 2.5), reach, gh);
@@ -490,29 +537,29 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
     gh->cell_base = 0;
     const size_t pe = 3 * (size_t)n, se = sub ? 3 * (size_t)ns : 0;
     WOL_TRY(c->in_stage.ensure(sizeof(double) * (pe + se)));
-    WOL_TRY(c->grids.ensure(sizeof(FrameGrid)));
-    WOL_TRY(c->cells.ensure(sizeof(int) * (size_t)(gh->ncell + 1)));
-    WOL_TRY(c->sorted.ensure(sizeof(double4) * (size_t)n));
+    WOL_TRY(S.grids.ensure(sizeof(FrameGrid)));
+    WOL_TRY(S.cells.ensure(sizeof(int) * (size_t)(gh->ncell + 1)));
+    WOL_TRY(S.sorted.ensure(sizeof(double4) * (size_t)n));
     WOL_TRY(c->cellid.ensure(sizeof(int) * (size_t)n));
     WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)n));
     HIP_TRY(hipMemcpyAsync(c->in_stage.p, pos, sizeof(double) * pe, hipMemcpyHostToDevice, c->stream));
     if (sub) HIP_TRY(hipMemcpyAsync(c->in_stage.as<double>() + pe, sub, sizeof(double) * se, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->grids.p, gh, sizeof(FrameGrid), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(S.grids.p, gh, sizeof(FrameGrid), hipMemcpyHostToDevice, c->stream));
     if (!c->grid_ev) HIP_TRY(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
     c->grid_copy_pending = true;
-    HIP_TRY(hipMemsetAsync(c->cells.p, 0, sizeof(int) * (size_t)(gh->ncell + 1), c->stream));
+    HIP_TRY(hipMemsetAsync(S.cells.p, 0, sizeof(int) * (size_t)(gh->ncell + 1), c->stream));
     FramesView<double> fv{c->in_stage.as<double>(), 3, 0, n};
     const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, 1);
-    hipLaunchKernelGGL(k_bin_count<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                       c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
-    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, c->grids.as<FrameGrid>(), c->cells.as<int>());
-    hipLaunchKernelGGL(k_scatter<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, c->grids.as<FrameGrid>(),
-                       c->cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), c->sorted.as<double4>(),
+    hipLaunchKernelGGL(k_bin_count<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, S.grids.as<FrameGrid>(),
+                       S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
+    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, S.grids.as<FrameGrid>(), S.cells.as<int>());
+    hipLaunchKernelGGL(k_scatter<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, S.grids.as<FrameGrid>(),
+                       S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), S.sorted.as<double4>(),
                        (float4*)nullptr);
-    sa->grid = c->grids.as<FrameGrid>();
-    sa->sorted = c->sorted.as<double4>();
-    sa->cell_start = c->cells.as<int>();
+    sa->grid = S.grids.as<FrameGrid>();
+    sa->sorted = S.sorted.as<double4>();
+    sa->cell_start = S.cells.as<int>();
     sa->n = n;
     sa->sub = sub ? c->in_stage.as<double>() + pe : nullptr;
     sa->ns = sub ? ns : n;
@@ -613,7 +660,7 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
             HIP_TRY(hipMemsetAsync(c->stat.p, 0, sizeof(unsigned long long) * 4 * (size_t)F, c->stream));
             out.stat = c->stat.as<unsigned long long>();
         }
-        WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out));
+        WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, !host));
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
             double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
@@ -683,8 +730,15 @@ int wol_ctx_destroy(wol_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    DevBuf* bufs[] = {&c->sorted, &c->sorted32, &c->cellid, &c->rank, &c->cells, &c->grids, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->level, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
+    DevBuf* bufs[] = {&c->cellid, &c->rank, &c->qbuf, &c->in_stage,
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
+    for (auto& S : c->sets) {
+        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release();
+        if (S.sorted_ev) (void)hipEventDestroy(S.sorted_ev);
+        if (S.free_ev) (void)hipEventDestroy(S.free_ev);
+    }
+    if (c->in_ev) (void)hipEventDestroy(c->in_ev);
+    if (c->sort_stream) { (void)hipStreamSynchronize(c->sort_stream); (void)hipStreamDestroy(c->sort_stream); }
     for (DevBuf* b : bufs) b->release();
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
@@ -720,6 +774,10 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
     } else if (k == "path") {
         if (value < 0 || value > 3) return fail(WOL_ERR_INVALID, "path must be 0..3");
         c->path = (int)value;
+    } else if (k == "inputs_resident") {
+        c->inputs_resident = value != 0.0;
+    } else if (k == "overlap") {
+        c->overlap = value != 0.0;
     } else if (k == "lds_sort") {
         c->lds_sort = value != 0.0;
     } else if (k == "time_kernels") {
@@ -754,10 +812,10 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
     }
     if (std::string(key) == "density_level") {  // tile-shape level of frame 0 of the last batch
         *value = -1;
-        if (c->level.p) {
+        if (c->last_set && c->last_set->level.p) {
             int v = 0;
             HIP_TRY(hipStreamSynchronize(c->stream));
-            HIP_TRY(hipMemcpy(&v, c->level.p, sizeof(int), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&v, c->last_set->level.p, sizeof(int), hipMemcpyDeviceToHost));
             *value = v;
         }
         return WOL_OK;
