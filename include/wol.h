@@ -112,6 +112,21 @@ int wol_lsi_frame(wol_ctx* ctx, const double* pos, int n, const double* sub, int
                   const double* box, double lowcut, double highcut, double* lsi_full,
                   double* num_lsi, int64_t* nvalid);
 
+/* ---- "next" row f-1: Willard-Chandler density field ---------------------------- */
+/* waterlib.f90:1286-1341 WillardDensityField (called by surface_library.densityGrid, :170-210):
+ * truncated-shifted Gaussian density (sigma = smoothlen, cut at 3 sigma) and its unit gradient at
+ * the nx*ny*nz grid points.  densvals (nx,ny,nz) and densnorms (nx,ny,nz,3) are Fortran-ordered, as
+ * f2py returns them; points with no water in range get NaN normals (0/0), as the reference.  Host
+ * pointers. */
+int wol_willard_density_field(wol_ctx* ctx, const double* pos, int n, const double* gridx, int nx,
+                              const double* gridy, int ny, const double* gridz, int nz,
+                              const double* box, double smoothlen, double* densvals, double* densnorms);
+/* waterlib.f90:1351-1398 WillardDensityPoints: the same at npts arbitrary points; densnorms is
+ * row-major [npts][3]. */
+int wol_willard_density_points(wol_ctx* ctx, const double* pos, int n, const double* pts, int npts,
+                               const double* box, double smoothlen, double* densvals,
+                               double* densnorms);
+
 /* ---- level 3: the tetOrderCalc frame loop (orderParam_lib.py:1458-1495) ------------------- */
 /* T frames of n waters each; water w of frame t is at frames + t*frame_stride + w*atom_stride
  * (strides in doubles).  boxes is host [T][3].  Per frame: q for every water (sub == pos branch),

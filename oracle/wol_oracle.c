@@ -563,3 +563,42 @@ int wolo_tet_order_traj(const double* frames, const double* boxes, int T, int n,
     free(nd);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Willard-Chandler density field.
+ * waterlib.f90:1351-1398 WillardDensityPoints (and :1286-1341 WillardDensityField, the same
+ * per-point arithmetic on a grid): truncated-shifted Gaussian density and its normalised gradient.
+ * The sum runs over ALL waters in index order, as in the reference.  densnorms is [npts][3]
+ * (row-major); points without any water inside 3*smoothlen get NaN normals (0/0), as the reference.
+ * ------------------------------------------------------------------------------------------ */
+void wolo_willard_density_points(const double* pos, int n, const double* pts, int npts, const double box[3],
+                                 double smoothlen, double* densvals, double* densnorms) {
+    const double pi = WOLO_PI;
+    double ib[3];
+    ibox_of(box, ib);
+    const double s2 = smoothlen * smoothlen;
+    const double pref = pow(2.0 * pi * s2, 1.5);
+    const double shiftterm = exp(-9.0 / 2.0) / pref;
+    const double cut = 9.0 * (smoothlen * smoothlen);
+    #pragma omp parallel for schedule(static)
+    for (int i = 0; i < npts; ++i) {
+        const double* a = pts + 3 * (size_t)i;
+        double densval = 0.0, nv[3] = {0.0, 0.0, 0.0};
+        for (int l = 0; l < n; ++l) {
+            double v[3];
+            for (int k = 0; k < 3; ++k) {
+                double t = a[k] - pos[3 * (size_t)l + k];        /* thisvec = apos - watpos */
+                v[k] = t - box[k] * round(t * ib[k]);
+            }
+            const double r2 = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+            if (r2 >= cut) continue;                              /* contributes exactly 0 */
+            const double expterm = -r2 / (2.0 * s2);
+            const double densfunc = exp(expterm) / pref - shiftterm;
+            densval += densfunc;
+            for (int k = 0; k < 3; ++k) nv[k] += -v[k] * (densfunc + shiftterm) / s2;
+        }
+        densvals[i] = densval;
+        const double nn = sqrt((nv[0] * nv[0] + nv[1] * nv[1]) + nv[2] * nv[2]);
+        for (int k = 0; k < 3; ++k) densnorms[3 * (size_t)i + k] = nv[k] / nn;
+    }
+}

@@ -185,3 +185,23 @@ def tet_order_traj(frames, boxes, lowCut=0.0, highCut=10.0, cells=True, qbins=50
                               qh.ctypes.data_as(_lp), C.c_int(qbins), dh.ctypes.data_as(_lp),
                               C.c_int(dbins), C.c_double(dbinwidth))
     return mean, var, qh, dh
+
+
+# ---- Willard-Chandler density field --------------------------------------
+def willarddensitypoints(pos, denspts, boxl, smoothlen):
+    """waterlib.willarddensitypoints -> (densvals[npts], densnorms[npts,3])"""
+    pos = _d(pos); pts = _d(denspts).reshape(-1, 3); box = _box(boxl)
+    dv = np.empty(len(pts)); dn = np.empty((len(pts), 3))
+    lib().wolo_willard_density_points(_p(pos), C.c_int(len(pos)), _p(pts), C.c_int(len(pts)), _p(box),
+                                      C.c_double(smoothlen), _p(dv), _p(dn))
+    return dv, dn
+
+
+def willarddensityfield(pos, gridx, gridy, gridz, boxl, smoothlen):
+    """waterlib.willarddensityfield -> (densvals[Nx,Ny,Nz], densnorms[Nx,Ny,Nz,3]) (Fortran order)"""
+    gx = _d(gridx).reshape(-1); gy = _d(gridy).reshape(-1); gz = _d(gridz).reshape(-1)
+    X, Y, Z = np.meshgrid(gx, gy, gz, indexing="ij")
+    pts = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    dv, dn = willarddensitypoints(pos, pts, boxl, smoothlen)
+    return (np.asfortranarray(dv.reshape(len(gx), len(gy), len(gz))),
+            np.asfortranarray(dn.reshape(len(gx), len(gy), len(gz), 3)))

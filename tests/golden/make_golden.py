@@ -174,6 +174,17 @@ def main():
                         lsidists=ld)
     print("waterlib_kat       tet q =", wp.getOrderParamq(posT[:1], posT, boxT))
 
+    # (11) SURVEY 8f row f-1: Willard-Chandler density field of a slab (waterlib.f90:1286-1398)
+    xyzW, boxesW = synth.slab_frames(700, 1, seed=12, n_vapour=5)
+    posW, boxW = xyzW[0], boxesW[0]
+    gx = np.linspace(1.0, boxW[0] - 1.0, 9); gy = np.linspace(0.5, boxW[1], 7); gz = np.linspace(-3.0, boxW[2] + 2.0, 14)
+    dv, dn = wl.willarddensityfield(posW, gx, gy, gz, boxW, 2.4)
+    pts = np.random.default_rng(3).random((200, 3)) * boxW * 1.2 - 3.0
+    pv, pn = wl.willarddensitypoints(posW, pts, boxW, 2.4)
+    np.savez_compressed(os.path.join(OUT, "willard_slab700.npz"), pos=posW, box=boxW, gridx=gx, gridy=gy, gridz=gz,
+                        smoothlen=2.4, densvals=dv, densnorms=dn, pts=pts, pts_densvals=pv, pts_densnorms=pn)
+    print("willard_slab700    max density %.4f, grid points without water in range: %d" % (dv.max(), int(np.isnan(dn[..., 0]).sum())))
+
 
 if __name__ == "__main__":
     main()

@@ -95,3 +95,13 @@ def test_analytic_cases(oracle):
     pair = np.array([[1.0, 2.0, 3.0], [2.0, 2.0, 3.0]])
     q, idx, dist, ang = oracle.getOrderParamq(pair, pair, np.array([90.0] * 3), full=True)
     assert np.all(ang == 180.0) and np.all(np.abs(q) < 1e-15) and idx[0, 0] == 1 and idx[1, 0] == 0
+
+
+def test_willard_density_field(oracle):
+    """SURVEY 8f row f-1 (waterlib.f90:1286-1398): the oracle reproduces the reference bit for bit"""
+    g = golden("willard_slab700")
+    dv, dn = oracle.willarddensityfield(g["pos"], g["gridx"], g["gridy"], g["gridz"], g["box"], float(g["smoothlen"]))
+    assert dv.shape == g["densvals"].shape and dv.flags.f_contiguous
+    assert np.array_equal(dv, g["densvals"]) and np.array_equal(dn, g["densnorms"], equal_nan=True)
+    pv, pn = oracle.willarddensitypoints(g["pos"], g["pts"], g["box"], float(g["smoothlen"]))
+    assert np.array_equal(pv, g["pts_densvals"]) and np.array_equal(pn, g["pts_densnorms"], equal_nan=True)

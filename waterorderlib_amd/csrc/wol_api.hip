@@ -557,6 +557,9 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
     hipLaunchKernelGGL(k_scatter<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, S.grids.as<FrameGrid>(),
                        S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), S.sorted.as<double4>(),
                        (float4*)nullptr);
+    // cells in original-index order: the shell kernels' floating-point sums become reproducible
+    hipLaunchKernelGGL(k_cell_order, dim3((gh->ncell + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream,
+                       S.grids.as<FrameGrid>(), S.cells.as<int>(), S.sorted.as<double4>());
     sa->grid = S.grids.as<FrameGrid>();
     sa->sorted = S.sorted.as<double4>();
     sa->cell_start = S.cells.as<int>();
@@ -1068,6 +1071,64 @@ int wol_lsi_frame(wol_ctx* c, const double* pos, int n, const double* sub, int n
     }
     if (nvalid) *nvalid = nv;
     return WOL_OK;
+}
+
+// ---- Willard-Chandler density field ---------------------------------------
+static int willard_impl(wol_ctx* c, const double* pos, int n, const double* pts, int64_t npts, const double* gx,
+                        int nx, const double* gy, int ny, const double* gz, int nz, const double* box,
+                        double smoothlen, double* densvals, double* densnorms) {
+    WOL_TRY(check_ctx(c));
+    if (!pos || !box || !densvals || !densnorms || n < 0 || npts < 0) return fail(WOL_ERR_INVALID, "willard: bad argument");
+    if (!(smoothlen > 0.0)) return fail(WOL_ERR_INVALID, "willard: smoothlen must be > 0");
+    if (npts == 0) return WOL_OK;
+    if (npts > 0x7fffffffLL) return fail(WOL_ERR_INVALID, "willard: too many points");
+    if (n == 0) {  // no waters: zero density, 0/0 normals (what the reference's empty loop leaves)
+        for (int64_t i = 0; i < npts; ++i) densvals[i] = 0.0;
+        for (int64_t i = 0; i < 3 * npts; ++i) densnorms[i] = std::nan("");
+        return WOL_OK;
+    }
+    ShellArgs sa;
+    // the `sub` slot of the set-up carries the query points in points mode
+    WOL_TRY(shell_setup(c, pos, n, pts, pts ? (int)npts : 0, box, 3.0 * smoothlen, &sa));
+    sa.lowsq = 0.0; sa.highsq = 0.0;
+    WillardArgs w;
+    w.gx = w.gy = w.gz = nullptr;
+    w.nx = nx; w.ny = ny; w.nz = nz; w.smoothlen = smoothlen;
+    const size_t ob = sizeof(double) * 4 * (size_t)npts;
+    WOL_TRY(c->out_stage.ensure(ob));
+    w.densvals = c->out_stage.as<double>();
+    w.densnorms = w.densvals + npts;
+    if (!pts) {
+        WOL_TRY(c->small.ensure(sizeof(double) * (size_t)(nx + ny + nz)));
+        double* d = c->small.as<double>();
+        HIP_TRY(hipMemcpyAsync(d, gx, sizeof(double) * nx, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d + nx, gy, sizeof(double) * ny, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d + nx + ny, gz, sizeof(double) * nz, hipMemcpyHostToDevice, c->stream));
+        w.gx = d; w.gy = d + nx; w.gz = d + nx + ny;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+    hipLaunchKernelGGL(k_willard, dim3((unsigned)((npts + WOL_BLOCK - 1) / WOL_BLOCK)), dim3(WOL_BLOCK), 0, c->stream, sa, w);
+    if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    HIP_TRY(hipMemcpyAsync(densvals, w.densvals, sizeof(double) * (size_t)npts, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(densnorms, w.densnorms, sizeof(double) * 3 * (size_t)npts, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+int wol_willard_density_field(wol_ctx* c, const double* pos, int n, const double* gridx, int nx, const double* gridy,
+                              int ny, const double* gridz, int nz, const double* box, double smoothlen,
+                              double* densvals, double* densnorms) {
+    if (!gridx || !gridy || !gridz || nx < 0 || ny < 0 || nz < 0) return fail(WOL_ERR_INVALID, "willard: bad grid");
+    return willard_impl(c, pos, n, nullptr, (int64_t)nx * ny * nz, gridx, nx, gridy, ny, gridz, nz, box, smoothlen,
+                        densvals, densnorms);
+}
+
+int wol_willard_density_points(wol_ctx* c, const double* pos, int n, const double* pts, int npts, const double* box,
+                               double smoothlen, double* densvals, double* densnorms) {
+    if (!pts && npts > 0) return fail(WOL_ERR_INVALID, "willard: pts must not be NULL");
+    return willard_impl(c, pos, n, pts, npts, nullptr, 0, nullptr, 0, nullptr, 0, box, smoothlen, densvals, densnorms);
 }
 
 // ---- level 3 ------------------------------------------------------------------------------

@@ -230,3 +230,71 @@ k_lsi(ShellArgs a, double high2sq, double* __restrict__ scratch, double* __restr
     lsi_full[row] = res;
     num_lsi[row] = cnt;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Willard-Chandler density field (waterlib.f90:1286-1341 WillardDensityField,
+// :1351-1398 WillardDensityPoints; surface_library.densityGrid :170-210 is its caller).
+// One lane per grid / query point gathers the waters within 3*smoothlen through the cell list
+// (the reference loops over all N waters per point: O(G*N)); truncated-shifted Gaussian density and
+// its normalised gradient in the reference's operation order.  The cells are first put in
+// original-index order (k_cell_order) so the floating-point sums are reproducible run to run.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_cell_order(const FrameGrid* __restrict__ grid, const int* __restrict__ cell_start, double4* __restrict__ sorted) {
+    const int c = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (c >= grid->ncell) return;
+    const int b = cell_start[grid->cell_base + c], e = cell_start[grid->cell_base + c + 1];
+    for (int i = b + 1; i < e; ++i) {  // insertion sort by original index; cells hold a handful of waters
+        const double4 v = sorted[i];
+        const long long key = __double_as_longlong(v.w);
+        int p = i;
+        while (p > b && __double_as_longlong(sorted[p - 1].w) > key) { sorted[p] = sorted[p - 1]; --p; }
+        sorted[p] = v;
+    }
+}
+
+struct WillardArgs {
+    const double* gx; const double* gy; const double* gz;  // grid mode (device); null = points mode (a.sub)
+    int nx, ny, nz;
+    double smoothlen;
+    double* densvals;   // grid: Fortran order (nx,ny,nz); points: [npts]
+    double* densnorms;  // grid: Fortran order (nx,ny,nz,3); points: row-major [npts][3]
+};
+
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_willard(ShellArgs a, WillardArgs w) {
+    const int64_t id = (int64_t)blockIdx.x * WOL_BLOCK + threadIdx.x;
+    const int64_t npts = w.gx ? (int64_t)w.nx * w.ny * w.nz : (int64_t)a.ns;
+    if (id >= npts) return;
+    double c[3];
+    if (w.gx) {  // id runs over (i, j, k) in Fortran order: i fastest
+        const int i = (int)(id % w.nx), j = (int)((id / w.nx) % w.ny), k = (int)(id / ((int64_t)w.nx * w.ny));
+        c[0] = w.gx[i]; c[1] = w.gy[j]; c[2] = w.gz[k];
+    } else {
+        c[0] = a.sub[3 * id]; c[1] = a.sub[3 * id + 1]; c[2] = a.sub[3 * id + 2];
+    }
+    const double pi = WOL_PI;
+    const double s2 = w.smoothlen * w.smoothlen;
+    const double pref = pow(2.0 * pi * s2, 1.5);
+    const double shiftterm = exp(-9.0 / 2.0) / pref;
+    const double cut = 9.0 * (w.smoothlen * w.smoothlen);
+    double densval = 0.0, n0 = 0.0, n1 = 0.0, n2 = 0.0;
+    // the reference forms thisvec = apos - watpos; the shared walker hands back watpos - apos after the
+    // same minimum-image step, and negation is exact (anint is odd), so v = -d bit for bit
+    wol_for_each_candidate(a, c, [&](int, double r2, double dx, double dy, double dz) {
+        if (r2 < cut) {
+            const double expterm = -r2 / (2.0 * s2);
+            const double densfunc = exp(expterm) / pref - shiftterm;
+            densval += densfunc;
+            const double g = densfunc + shiftterm;  // -thisvec * (densfunc + shiftterm) / s2, left to right
+            n0 += (dx * g) / s2; n1 += (dy * g) / s2; n2 += (dz * g) / s2;
+        }
+    });
+    const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+    w.densvals[id] = densval;
+    if (w.gx) {
+        w.densnorms[id] = n0 / nn; w.densnorms[npts + id] = n1 / nn; w.densnorms[2 * npts + id] = n2 / nn;
+    } else {
+        w.densnorms[3 * id] = n0 / nn; w.densnorms[3 * id + 1] = n1 / nn; w.densnorms[3 * id + 2] = n2 / nn;
+    }
+}

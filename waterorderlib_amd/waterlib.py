@@ -85,3 +85,31 @@ def lsidists(refpos, neighpos, boxl, nneighpos=None):
     _lib.check(_lib.load().wol_lsi_dists(_lib.default_context().handle, _lib.ptr(ref), _lib.ptr(nb), len(nb),
                                          _lib.ptr(box), _lib.ptr(out)))
     return out
+
+
+def willarddensityfield(pos, gridx, gridy, gridz, boxl, smoothlen, npos=None, nx=None, ny=None, nz=None):
+    """densvals,densnorms = willarddensityfield(pos,gridx,gridy,gridz,boxl,smoothlen,[npos,nx,ny,nz])
+    -- waterlib.f90:1286-1341 (the call of surface_library.densityGrid, :197-199).  Fortran-ordered
+    (nx,ny,nz) and (nx,ny,nz,3) arrays; the grid vectors may have shape (n,) or (1,n) as f2py accepts."""
+    pos = _pos(pos, "pos"); box = _lib.box3(boxl)
+    gx = np.ascontiguousarray(np.asarray(gridx, dtype=np.float64).reshape(-1))
+    gy = np.ascontiguousarray(np.asarray(gridy, dtype=np.float64).reshape(-1))
+    gz = np.ascontiguousarray(np.asarray(gridz, dtype=np.float64).reshape(-1))
+    dv = np.empty((len(gx), len(gy), len(gz)), dtype=np.float64, order="F")
+    dn = np.empty((len(gx), len(gy), len(gz), 3), dtype=np.float64, order="F")
+    _lib.check(_lib.load().wol_willard_density_field(_lib.default_context().handle, _lib.ptr(pos), len(pos),
+                                                     _lib.ptr(gx), len(gx), _lib.ptr(gy), len(gy), _lib.ptr(gz),
+                                                     len(gz), _lib.ptr(box), float(smoothlen), _lib.ptr(dv),
+                                                     _lib.ptr(dn)))
+    return dv, dn
+
+
+def willarddensitypoints(pos, denspts, boxl, smoothlen, npos=None, npts=None):
+    """densvals,densnorms = willarddensitypoints(pos,denspts,boxl,smoothlen,[npos,npts]) -- waterlib.f90:1351-1398"""
+    pos = _pos(pos, "pos"); pts = _pos(denspts, "denspts"); box = _lib.box3(boxl)
+    dv = np.empty(len(pts), dtype=np.float64)
+    dn = np.empty((len(pts), 3), dtype=np.float64)
+    _lib.check(_lib.load().wol_willard_density_points(_lib.default_context().handle, _lib.ptr(pos), len(pos),
+                                                      _lib.ptr(pts), len(pts), _lib.ptr(box), float(smoothlen),
+                                                      _lib.ptr(dv), _lib.ptr(dn)))
+    return dv, np.asfortranarray(dn)
