@@ -94,7 +94,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run the exchange step goes through RCCL even with one rank (lets the
+    # collective path be rehearsed on a one-GPU box); a plain `python bench.py` has no process group
+    distributed = world > 1 or ("LOCAL_RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0 and world > 1:
@@ -135,23 +138,23 @@ def main():
         mean = torch.cat([r.mean for r in results])
         var = torch.cat([r.var for r in results])
         local = engine.TrajResult(mean, var, qh, dh)
-        return engine.reduce_traj_result(local, world * count * F) if world > 1 else local
+        return engine.reduce_traj_result(local, world * count * F) if distributed else local
 
     if args.warmup > 0:
         run_job(0, args.warmup)  # untimed: also loads every kernel the timed region uses
     torch.cuda.synchronize()
     ctx.kernel_time(reset=True)
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     total = run_job(args.warmup, args.steps)
     torch.cuda.synchronize()
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -202,7 +205,7 @@ def main():
             pos_host = batches[args.warmup][0].to(torch.float64).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(pos_host, box, min(args.cpu_sample_waters, n), len(os.sched_getaffinity(0)))
         print(json.dumps(out))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

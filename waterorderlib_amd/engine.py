@@ -105,7 +105,7 @@ def reduce_traj_result(local, T_total, group=None):
     single-GPU one.  `local` holds this rank's shard (frames [frame_offset, frame_offset+len(mean)))."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     world = dist.get_world_size(group)
     as_t = lambda a, dt: a if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a)).to(dt)
