@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--path", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-waters", type=int, default=10000)
+    ap.add_argument("--search-rows", type=int, default=-1, help="proposal kernel: 1 row-merged tiles, 0 3-D tiles (default: library default)")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run "
                          "(default: profiles/r01_hbm_traffic_pmc.json when the workload matches it)")
@@ -120,6 +121,8 @@ def main():
         ctx.set_option("cell_width", args.cell_width)
     if args.path:
         ctx.set_option("path", args.path)
+    if args.search_rows >= 0:
+        ctx.set_option("search_rows", args.search_rows)
 
     total_steps = args.warmup + args.steps
     # every step owns its frames; generated (untimed) up front so the timed region only reads HBM

@@ -295,6 +295,31 @@ def test_two_stream_overlap_option_gives_identical_results():
     ctx.close()
 
 
+def test_both_proposal_kernels_agree_and_match_oracle(wp, oracle):
+    """the row-merged proposal kernel (default) and the 3-D tile one (fallback for frames above 2^20 waters) feed
+    the same certification: identical results, full outputs included; odd box shapes exercise the tile edges"""
+    from waterorderlib_amd import _lib, synth
+    oracle.set_threads(8)
+    cases = [(synth.water_frames(6000, 1, seed=91), None),
+             (synth.water_frames(9000, 1, seed=92, box=np.array([93.0, 41.0, 70.5])), None),   # long rows, few rows
+             (synth.water_frames(5000, 1, seed=93, box=np.array([14.2, 150.0, 70.0])), None),  # 3 cells along x
+             (synth.slab_frames(8000, 1, seed=94, n_vapour=30), None)]
+    for (xyz, boxes), _ in cases:
+        pos, box = xyz[0], boxes[0]
+        res = {}
+        for rows in (1, 0):
+            c = _lib.Context(0)
+            c.set_option("path", 3)
+            c.set_option("search_rows", rows)
+            res[rows] = wp.getOrderParamq(pos, pos, box, full=True, ctx=c)
+            c.close()
+        q_o, idx_o, dist_o, ang_o = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+        for rows in (1, 0):
+            check_full(res[rows], q_o, idx_o, dist_o, ang_o)
+        for a, b in zip(res[0], res[1]):
+            assert np.array_equal(a, b, equal_nan=True)
+
+
 # ---- SURVEY 8f row f-1: Willard-Chandler density field ---------------------------------------------
 DENS_RTOL = 1e-12   # device exp() vs glibc exp(): a few ulp on each Gaussian term
 NORM_ATOL = 1e-10   # unit normals; looser where the gradient nearly cancels

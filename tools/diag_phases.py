@@ -17,11 +17,14 @@ fr = bench.make_frames(torch, torch.from_numpy(base).to(dev), box, F, 1, 0.3, to
 ctx = _lib.Context(0)
 if len(sys.argv) > 1:
     ctx.set_option("cell_width", float(sys.argv[1]))
+rows = os.environ.get("WOL_DIAG_ROWS", "1") == "1"
+ctx.set_option("search_rows", 1 if rows else 0)
 for rep in range(2):
     engine.tet_order_traj(fr, boxes, ctx=ctx)
     torch.cuda.synchronize()
-    names = ["tail+decode", "phase1 counts", "phase2 scan", "phase3+4 stage", "query sweep"]
-    vals = [ctx.counter("stamp%d" % i) for i in range(5)]
+    names = (["tail+decode", "rows/pieces", "pass A count", "scan", "pass B place", "sweep"] if rows else
+             ["tail+decode", "phase1 counts", "phase2 scan", "phase3+4 stage", "query sweep"])
+    vals = [ctx.counter("stamp%d" % i) for i in range(len(names))]
     ctx.counter("stamp0z")
 import time
 torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared wol_api.hip -o libwol.so
 #include "wol_kernels.hip"
 #include "wol_search_fast.hip"
+#include "wol_search_rows.hip"
 #include "wol_shell.hip"
 
 #include <cmath>
@@ -98,6 +99,7 @@ struct wol_ctx {
     int next_set = 0;
     hipStream_t sort_stream = nullptr;
     hipEvent_t in_ev = nullptr;
+    bool search_rows = true;  // proposal kernel: row-merged tiles (wol_search_rows.hip); false = 3-D tiles (wol_search_fast.hip)
     bool overlap = false;  // measured on MI355X: the sort and the search contend for the same CU slots and
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
@@ -181,6 +183,7 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
     g->nlev = 0;
     g->ntiles = 0;
     g->scale = 1.f; g->tmax = 0.f; g->S = 1.0; g->eps_units = 0;
+    g->row_tiles_max = 0; g->row_eps_units = 0;
     if (g->nc[0] >= 3 && g->nc[1] >= 3 && g->nc[2] >= 3) {
         const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
@@ -246,6 +249,52 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
         const double eps = 2.0 * 1.7320508 * (rmax * g->scale) * (2.0 * ulpM) + 1.5;
         g->eps_units = (int)std::ceil(eps * 1.25) + 2;
         g->fast_ok = (high >= rmax) ? 1 : 0;
+
+        // ---- tiles of the row-merged kernel (wol_search_rows.hip): sx cells x ry rows in one z layer;
+        //      staged = (ry + 2) triples of three z rows, sx + 2 cells long ----
+        g->row_tiles_max = 0;
+        int rmax_sx = 1;
+        for (int l = 0; l < WOL_NLEV; ++l) {
+            const double w = wpc * lev_mult[l] / 1.10;
+            double best = -1.0;
+            int bsx = 1, bry = 1, bntx = g->nc[0], bnty = g->nc[1];
+            for (int sx0 = 1; sx0 <= std::min(g->nc[0], WOL_ROWS_MAXSX); ++sx0) {
+                const int ntx = (g->nc[0] + sx0 - 1) / sx0, sx = (g->nc[0] + ntx - 1) / ntx;  // equalised
+                if (sx != sx0) continue;
+                for (int ry0 = 1; ry0 <= std::min(g->nc[1], WOL_ROWS_MAXRY); ++ry0) {
+                    const int nty = (g->nc[1] + ry0 - 1) / ry0, ry = (g->nc[1] + nty - 1) / nty;
+                    if (ry != ry0) continue;
+                    const double q = sx * ry * w;
+                    const bool unit = (sx == 1 && ry == 1);
+                    if (q > (double)WOL_ROWS_TARGET && !unit) continue;
+                    const double staged = 3.0 * (ry + 2) * (sx + 2) * w;
+                    if (staged * 1.12 + (ry + 2) > 2.0 * WOL_ROWS_CAPP && !unit) continue;
+                    if ((ry + 2) * (((sx + 2) * WOL_XSUB + 2) / 2) > WOL_ROWS_BINW) continue;
+                    // fill of the block's lanes first (5 % bands), then the staging ratio
+                    const double band = std::floor(q / (0.05 * WOL_ROWS_TARGET));
+                    const double score = band - staged / (q * 100.0);
+                    if (score > best) { best = score; bsx = sx; bry = ry; bntx = ntx; bnty = nty; }
+                }
+            }
+            g->row_sx[l] = (short)bsx; g->row_ry[l] = (short)bry;
+            g->row_ntx[l] = (short)bntx; g->row_nty[l] = (short)bnty;
+            g->row_ntiles[l] = bntx * bnty * g->nc[2];
+            g->row_tiles_max = std::max(g->row_tiles_max, g->row_ntiles[l]);
+            rmax_sx = std::max(rmax_sx, bsx);
+        }
+        {
+            // per-axis coordinate magnitudes: x up to half the staged tile length, y half the staged rows
+            // (both + one cell-local value), z one and a half cells; errors add in quadrature over the axes
+            auto ulp_of = [&](double ext) {
+                const double Mk = ext * g->scale;
+                return std::ldexp(1.0, (int)std::ceil(std::log2(Mk)) - 24);
+            };
+            const double ux = ulp_of(0.5 * (rmax_sx + 2) * g->cw[0] + g->cw[0]);
+            const double uy = ulp_of(0.5 * (WOL_ROWS_MAXRY + 2) * g->cw[1] + g->cw[1]);
+            const double uz = ulp_of(2.0 * g->cw[2]);
+            const double eps = 2.0 * (rmax * g->scale) * 2.0 * std::sqrt(ux * ux + uy * uy + uz * uz) + 1.5;
+            g->row_eps_units = (int)std::ceil(eps * 1.25) + 2;
+        }
     }
     return true;
 }
@@ -376,10 +425,11 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         c->grid_copy_pending = true;
         bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
         int tiles_max = 0;
+        const bool rows_kernel = c->search_rows && n <= (1 << WOL_SLOT_BITS);
         for (int f = 0; f < F && use_fast; ++f) {
             if (gh[f].maxshell < 0) continue;
             if (!gh[f].fast_ok) use_fast = false;
-            tiles_max = std::max(tiles_max, gh[f].ntiles);
+            tiles_max = std::max(tiles_max, rows_kernel ? gh[f].row_tiles_max : gh[f].ntiles);
         }
         if (tiles_max == 0) use_fast = false;
         float4* s32 = nullptr;
@@ -475,16 +525,19 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             fa.prop = c->prop.as<int4>();
             fa.prop_key = c->prop_key.as<int>();
             fa.stamps = nullptr;
+            fa.rows = rows_kernel ? 1 : 0;
 #ifdef WOL_PHASE_STAMPS
             WOL_TRY(c->stamps.ensure(sizeof(unsigned long long) * 8));
             fa.stamps = c->stamps.as<unsigned long long>();
 #endif
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = 0;
-            WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
+            if (rows_kernel) WOL_TRY(resident_grid(c, k_search_rows, WOL_ROWS_BLOCK, 0, ftotal, &fgrid, 0));
+            else WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-            hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
+            if (rows_kernel) hipLaunchKernelGGL(k_search_rows, dim3(fgrid), dim3(WOL_ROWS_BLOCK), 0, c->stream, fa);
+            else hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
             const int64_t wtotal = (int64_t)F * n;
             int ggrid = 0;
@@ -779,6 +832,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->path = (int)value;
     } else if (k == "inputs_resident") {
         c->inputs_resident = value != 0.0;
+    } else if (k == "search_rows") {
+        c->search_rows = value != 0.0;
     } else if (k == "overlap") {
         c->overlap = value != 0.0;
     } else if (k == "lds_sort") {

@@ -36,6 +36,11 @@ struct FrameGrid {
     short lev_ntx[WOL_NLEV], lev_nty[WOL_NLEV], lev_ntz[WOL_NLEV];
     int lev_ntiles[WOL_NLEV];
     int ntiles;         // max over the levels (launch bound)
+    // tiles of the row-merged proposal kernel (wol_search_rows.hip): sx cells by ry rows in one z layer
+    short row_sx[WOL_NLEV], row_ry[WOL_NLEV], row_ntx[WOL_NLEV], row_nty[WOL_NLEV];
+    int row_ntiles[WOL_NLEV];
+    int row_tiles_max;
+    int row_eps_units;  // its bound on |fp32 key - exact d^2 * S| (longer tiles: larger coordinates)
     float scale;        // sqrt(S): staged coordinates are multiplied by it so d^2 comes out in key units
     float tmax;         // 2^23 + 2^21 - 1: saturation of the biased squared distance
     double S;           // key units per A^2 (2^21 / r2max)

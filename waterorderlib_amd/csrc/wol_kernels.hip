@@ -98,7 +98,7 @@ k_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __re
         u = v.x * g.box.ib[0]; u -= floor(u); w.x = (float)((u * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
         u = v.y * g.box.ib[1]; u -= floor(u); w.y = (float)((u * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
         u = v.z * g.box.ib[2]; u -= floor(u); w.z = (float)((u * (double)g.nc[2] - (double)cz) * g.cw[2] * (double)g.scale);
-        w.w = 0.f;
+        w.w = (float)cx;  // cell number along x (k_search_rows builds tile coordinates from it)
         sorted32[o + dst] = w;
     }
 }
@@ -204,7 +204,7 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
                 w.x = (float)((ux * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
                 w.y = (float)((uy * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
                 w.z = (float)((uz * (double)nz - (double)cz) * g.cw[2] * (double)g.scale);
-                w.w = 0.f;
+                w.w = (float)cx;  // cell number along x (k_search_rows builds tile coordinates from it)
                 so32[dst] = w;
             }
         }
@@ -344,7 +344,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
                 w.x = (float)((ux * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
                 w.y = (float)((uy * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
                 w.z = (float)((uz * (double)nz - (double)cz) * g.cw[2] * (double)g.scale);
-                w.w = 0.f;
+                w.w = (float)cx;  // cell number along x (k_search_rows builds tile coordinates from it)
                 so32[dst] = w;
             }
         }

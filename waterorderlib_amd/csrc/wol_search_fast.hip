@@ -42,6 +42,9 @@
 #define WOL_CP 16             // row stride of the cell tables: sx + 3 <= 15
 #define WOL_FAST_MAXCELL 20   // a cell with more waters sends its tile to the exact path (span <= 64 entries)
 #define WOL_ID_BITS 12        // key = d2 (20 bits) << 12 | entry index in the staged tile
+#ifndef WOL_XSUB
+#define WOL_XSUB 4            // fine x bins per cell of the row-merged kernel (wol_search_rows.hip)
+#endif
 
 // Diagnostic build only (-DWOL_PHASE_STAMPS): per-phase shader-clock totals of k_search_fast, added
 // by lane 0 of every block into a buffer that nothing else reads.  The product build has no stamps.
@@ -75,6 +78,7 @@ struct FastArgs {
     int4* prop;             // [F][n] by sorted slot: sorted slots of the four proposed neighbours
     int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
     unsigned long long* stamps;  // diagnostic builds only
+    int rows;               // 1: proposals come from k_search_rows (x reach counted in fine bins, its own eps)
 };
 
 // sorted insert of `key` into k0 <= k1 <= ... <= k4 (the largest falls off): new k_i is the median of
@@ -500,6 +504,25 @@ k_search_fast(FastArgs a) {
     }
 }
 
+// radius around a water inside which the proposal kernel is guaranteed to have seen every water: one cell
+// width plus the distance to the nearest wall of its cell -- along x of its fine bin when the proposals
+// come from k_search_rows, whose x window is counted in bins (fp32 binning there vs fp64 here: 1e-5 A margin)
+__device__ __forceinline__ double wol_guaranteed_radius(const double c[3], const FrameGrid& g, int rows) {
+    double rg = __builtin_huge_val();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        double fr;
+        (void)wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr);
+        double wall = fmin(fr, 1.0 - fr) * g.cw[k];
+        if (k == 0 && rows) {
+            const double ff = fr * (double)WOL_XSUB - floor(fr * (double)WOL_XSUB);
+            wall = fmin(ff, 1.0 - ff) * (g.cw[0] / (double)WOL_XSUB);
+        }
+        rg = fmin(rg, g.cw[k] + wall);
+    }
+    return rg - 1e-5;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel 2: certification + epilogue, one lane per water in sorted order.  Re-evaluates the four
 // proposed neighbours from the fp64 coordinates with the reference's arithmetic, accepts when the
@@ -535,6 +558,7 @@ k_finish_fast(FastArgs a) {
         const FrameGrid& g = a.grids[f];
         if (g.maxshell < 0) continue;  // all-pairs frame
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+        const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
         const int kd3 = live ? a.prop_key[w] : 0;
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
@@ -562,18 +586,11 @@ k_finish_fast(FastArgs a) {
                 dmax = fmax(dmax, dist[k]);
                 emax = fmax(emax, fmax(fabs(vx[k]) * g.box.ib[0], fmax(fabs(vy[k]) * g.box.ib[1], fabs(vz[k]) * g.box.ib[2])));
             }
-            double rg = __builtin_huge_val();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                double fr;
-                (void)wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr);
-                rg = fmin(rg, g.cw[k] + fmin(fr, 1.0 - fr) * g.cw[k]);
-            }
-            rg -= 1e-6;
+            const double rg = wol_guaranteed_radius(c, g, a.rows);
             const double d3s = (dmax * dmax) * g.S;
             // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity, so the
             // vectors CosAngle3 sees are exactly (apos + v) - apos
-            if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)g.eps_units || !(emax < 0.49)) {
+            if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)eps_u || !(emax < 0.49)) {
                 slow = true;
             } else {
                 double wx[4], wy[4], wz[4], rn[4];
@@ -654,17 +671,10 @@ k_finish_fast(FastArgs a) {
                 top4_insert(t, dist, (int)__double_as_longlong(n3.w), 3);
             all_in = all_in && in_mask;
             // radius the 27-cell stencil guarantees to be complete around this water
-            double rg = __builtin_huge_val();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                double fr;
-                (void)wol_cell_coord(c[k], g.box.ib[k], g.nc[k], &fr);
-                rg = fmin(rg, g.cw[k] + fmin(fr, 1.0 - fr) * g.cw[k]);
-            }
-            rg -= 1e-6;
+            const double rg = wol_guaranteed_radius(c, g, a.rows);
             // the exact 4th key must also agree with the fp32 proposal (guards the error bound itself)
             const double d3s = (t.d3 * t.d3) * g.S;
-            if (!all_in || t.n != 4 || !(t.d3 <= rg) || fabs(d3s - (double)kd3) > (double)g.eps_units) {
+            if (!all_in || t.n != 4 || !(t.d3 <= rg) || fabs(d3s - (double)kd3) > (double)eps_u) {
                 slow = true;
             } else {
                 // neighbours in exact rank order (t.s* = position 0..3 in the proposal)

@@ -1,0 +1,377 @@
+// wol_search_rows.hip -- the proposal kernel, row-merged form (included by wol_api.hip).
+//
+// Same contract as k_search_fast (wol_search_fast.hip): per water the sorted slots of four proposed
+// neighbours and the 4th fp32 key, certified later by k_finish_fast with the reference's fp64
+// arithmetic.  What changes is how a tile is laid out in LDS, which is what the sweep's cost hangs on:
+//
+//   tile   = sx cells along x by ry cell rows along y in ONE z layer (long in x: whole rows if they fit);
+//   staged = for every y row of the tile and its two y-halo rows, the three z rows (z-1, z, z+1) MERGED
+//            into one array ordered by a fine x bin (WOL_XSUB bins per cell) -- a "triple".  A wave per
+//            staged row reads the row's three contiguous pieces of the cell-sorted fp32 array (left halo
+//            cell, the tile's cells, right halo cell; periodic images come out shifted because the
+//            coordinates are built from staged cell numbers), counts into LDS bin counters with a
+//            returning atomic (= rank inside the bin), a scan turns counts into starts, a second pass
+//            over the same (L2-hot) rows places every water.  Pair records as in k_search_fast.
+//   sweep  = a water in row y looks at THREE contiguous windows, the bins [b-XSUB, b+XSUB] of triples
+//            y-1, y, y+1 (b = its own fine bin): an x reach of at least one cell width plus the distance
+//            to its bin wall, against nine spans of three whole cells before -- 25 % fewer candidates,
+//            and three trip counts (wave maxima) per water instead of nine.
+//
+// Self-exclusion costs nothing: the bias of the fixed-point conversion is 2^23 - 1, so the water's own
+// record (d2 = 0) leaves the [2^23, 2^24) binade and its key reads as saturated; every other key is d2 - 1.
+#pragma once
+
+#ifndef WOL_ROWS_BLOCK
+#define WOL_ROWS_BLOCK 512
+#endif
+#ifndef WOL_ROWS_CAPP
+#define WOL_ROWS_CAPP 1280     // staged PAIRS per tile (with the tables: < 53 KiB of LDS, three blocks per CU)
+#endif
+#define WOL_ROWS_PADP 8        // head-room pairs behind the last triple (incl. the dummy pair)
+#ifndef WOL_XSUB
+#define WOL_XSUB 4             // fine x bins per cell
+#endif
+#define WOL_ROWS_MAXRY 30
+#define WOL_ROWS_MAXTRIP (WOL_ROWS_MAXRY + 2)
+#define WOL_ROWS_MAXROWS (3 * WOL_ROWS_MAXTRIP)
+#define WOL_ROWS_MAXSX (252 / WOL_XSUB - 2)   // (sx + 2) * XSUB bins <= 252 (four bins per lane in the scan)
+#define WOL_ROWS_BINW 704      // 32-bit words of bin counters: sum over the triples of ceil((bins + 1) / 2)
+#define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
+#define WOL_ROWS_TARGET ((WOL_ROWS_BLOCK * 97) / 100)
+#ifndef WOL_ROWS_WPS
+#define WOL_ROWS_WPS 4         // two blocks per CU; at 6 (three blocks, 80 VGPRs) the staging slots spill: measured slower
+#endif
+#ifndef WOL_ROWS_RELOAD
+#define WOL_ROWS_RELOAD 0
+#endif
+
+// one window of candidate pairs against the lane's water (cf. wol_fast_span; bias 2^23 - 1)
+// Records are split in two arrays of 16-byte halves, A = (x0, x1, y0, y1) and B = (z0, z1, id0, id1) per pair:
+// a ds_read_b128 is served in groups of 16 lanes that conflict on (address / 16) mod 16, and consecutive pairs of
+// one array fall on consecutive classes (interleaved 32-byte records would use every other class only).
+#define WOL_ROWS_B_OFF (16 * (WOL_ROWS_CAPP + WOL_ROWS_PADP))   // byte offset of array B behind array A
+__device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes, int pb, int np, int dummy_off,
+                                              wol_f2 xi, wol_f2 yi, wol_f2 zi, unsigned tmaxbits, unsigned& k0,
+                                              unsigned& k1, unsigned& k2, unsigned& k3, unsigned& k4) {
+    const wol_f2 bias = {8388607.0f, 8388607.0f};
+    int off = pb * 16;
+    const int end = (pb + np) * 16;
+    int tmax_np = np;
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) tmax_np = max(tmax_np, __shfl_xor(tmax_np, sh, 64));
+    const int T = __builtin_amdgcn_readfirstlane(tmax_np);
+    for (int t = 0; t < T; ++t, off += 16) {
+        const int o = (off < end) ? off : dummy_off;
+        const float4 a = *reinterpret_cast<const float4*>(rec_bytes + o);
+        const float4 b = *reinterpret_cast<const float4*>(rec_bytes + o + WOL_ROWS_B_OFF);
+        const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
+        wol_f2 tt = __builtin_elementwise_fma(dx, dx, bias);
+        tt = __builtin_elementwise_fma(dy, dy, tt);
+        tt = __builtin_elementwise_fma(dz, dz, tt);
+        // id word = entry << 20 | slot: v_alignbit_b32 shifts the squared distance above the entry number
+        const unsigned key0 = __builtin_amdgcn_alignbit(min(__float_as_uint(tt.x), tmaxbits), __float_as_uint(b.z), WOL_SLOT_BITS);
+        const unsigned key1 = __builtin_amdgcn_alignbit(min(__float_as_uint(tt.y), tmaxbits), __float_as_uint(b.w), WOL_SLOT_BITS);
+        wol_top5_insert(key0, k0, k1, k2, k3, k4);
+        wol_top5_insert(key1, k0, k1, k2, k3, k4);
+    }
+}
+
+__global__ void __launch_bounds__(WOL_ROWS_BLOCK, WOL_ROWS_WPS)
+k_search_rows(FastArgs a) {
+    __shared__ float4 rec[2 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)];  // pair records: array A (x0,x1,y0,y1), then array B (z0,z1,id0,id1)
+    __shared__ unsigned bins[WOL_ROWS_BINW];                     // per triple: 16-bit counters, then exclusive starts
+    __shared__ int rsrc[WOL_ROWS_MAXROWS * 3];                   // staged row: first slot of its three pieces
+    __shared__ unsigned short rcnt[WOL_ROWS_MAXROWS * 3];        // ... and their lengths
+    __shared__ int rpre[WOL_ROWS_MAXROWS + 1];                   // staged waters before the row
+    __shared__ unsigned char rowat[(2 * WOL_ROWS_CAPP) / 64 + 1];  // row holding staged water 64 * c
+    __shared__ int tbase[WOL_ROWS_MAXTRIP + 1];                  // first entry of the triple (even)
+    __shared__ int ttot[WOL_ROWS_MAXTRIP];
+    __shared__ int qrow[WOL_ROWS_MAXRY + 2];                     // own rows -> first query number
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = WOL_ROWS_BLOCK / 64;
+    const bool aff = a.xcd_affine != 0;
+    const int fstep = aff ? 8 : 1;
+    const int tstep = aff ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    int f = aff ? (int)(blockIdx.x & 7) : 0;
+    int tile = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    float* __restrict__ recf = reinterpret_cast<float*>(rec);
+    float* __restrict__ recg = recf + 4 * (WOL_ROWS_CAPP + WOL_ROWS_PADP);   // array B
+    // the wave's waters are dealt so that each of ds_read_b128's four lane groups holds 16 CONSECUTIVE waters
+    // (their windows overlap: equal addresses broadcast, neighbouring ones fall on different banks)
+    const int l5 = lane & 31;
+    const bool g0 = (l5 < 4) || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+    const int lrank = (lane & 32) + (g0 ? (l5 < 4 ? l5 : l5 < 16 ? l5 - 8 : l5 - 12)
+                                        : 16 + (l5 < 12 ? l5 - 4 : l5 < 20 ? l5 - 8 : l5 - 16));
+#ifdef WOL_PHASE_STAMPS
+    unsigned long long stamp_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+
+    auto tiles_of = [&](int ff) -> int {
+        if (ff >= a.F) return 0;
+        const FrameGrid& gg = a.grids[ff];
+        return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.row_ntiles[a.level[ff]];
+    };
+    int nt_f = tiles_of(f);
+    for (;; tile += tstep) {
+        while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
+        if (f >= a.F) break;
+        const FrameGrid& g = a.grids[f];
+        const int lev = a.level[f];
+        const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
+        const int gsx = g.row_sx[lev], gry = g.row_ry[lev];
+        const int gntx = g.row_ntx[lev], gnty = g.row_nty[lev];
+        const int ntxy = gntx * gnty;
+        const int cz = (int)(((float)tile + 0.5f) / (float)ntxy);
+        const int trem = tile - cz * ntxy;
+        const int ty = (int)(((float)trem + 0.5f) / (float)gntx);
+        const int tx = trem - ty * gntx;
+        const int x0 = tx * gsx, sxe = min(gsx, nx - x0);
+        const int y0 = ty * gry, re = min(gry, ny - y0);
+        const int ntrip = re + 2, nrows = 3 * ntrip;
+        const int nb = (sxe + 2) * WOL_XSUB, nbw = (nb + 2) >> 1;   // bins, words per triple (nb + 1 halves)
+        const unsigned short* __restrict__ bins16 = reinterpret_cast<const unsigned short*>(bins);
+        const float4* __restrict__ sp32 = a.sorted32 + (int64_t)f * a.n;
+        const int* __restrict__ cs = a.cell_start + g.cell_base;
+        const int64_t frame_off = (int64_t)f * a.n;
+        const float fx = (float)(g.cw[0] * (double)g.scale), fy = (float)(g.cw[1] * (double)g.scale);
+        const float fz = (float)(g.cw[2] * (double)g.scale);
+        const float inv_wf = (float)WOL_XSUB / fx;
+        const float xc = 0.5f * (float)(sxe + 2), yc = 0.5f * (float)(re + 2);
+
+        __syncthreads();           // the previous tile is done with the LDS tables
+        WOL_STAMP(0);
+        // ---- phase 0/1: counters to zero; one thread per staged row: its three pieces ----
+        for (int i = tid; i < ntrip * nbw; i += WOL_ROWS_BLOCK) bins[i] = 0u;
+        if (tid == 0) s_flag = 0;
+        if (tid < nrows) {
+            const int t = (int)(((float)tid + 0.5f) * (1.0f / 3.0f)), dzk = tid - 3 * t;
+            const int gz = wol_wrap_cell(cz + dzk - 1, nz), gy = wol_wrap_cell(y0 + t - 1, ny);
+            const int rb = (gz * ny + gy) * nx;
+            const int cl = wol_wrap_cell(x0 - 1, nx), cr = wol_wrap_cell(x0 + sxe, nx);
+            const int sl = cs[rb + cl], el = cs[rb + cl + 1];
+            const int sb = cs[rb + x0], eb = cs[rb + x0 + sxe];
+            const int sr = cs[rb + cr], er = cs[rb + cr + 1];
+            rsrc[3 * tid] = sl; rsrc[3 * tid + 1] = sb; rsrc[3 * tid + 2] = sr;
+            rcnt[3 * tid] = (unsigned short)min(el - sl, 65535);
+            rcnt[3 * tid + 1] = (unsigned short)min(eb - sb, 65535);
+            rcnt[3 * tid + 2] = (unsigned short)min(er - sr, 65535);
+        }
+        __syncthreads();
+        if (wave == 0) {           // staged waters before each row (nrows <= 96: two rounds of 64)
+            int run = 0;
+            for (int r0 = 0; r0 < nrows; r0 += 64) {
+                const int r = r0 + lane;
+                const int len = (r < nrows) ? (int)rcnt[3 * r] + (int)rcnt[3 * r + 1] + (int)rcnt[3 * r + 2] : 0;
+                int inc = len;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += v;
+                }
+                if (r < nrows) rpre[r] = run + inc - len;
+                run += __shfl(inc, 63, 64);
+            }
+            if (lane == 0) {
+                rpre[nrows] = run;
+                if (run + ntrip > 2 * WOL_ROWS_CAPP) s_flag = 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (run + ntrip <= 2 * WOL_ROWS_CAPP && lane * 64 < run) {   // <= 40 chunks of 64 staged waters
+                const int w = lane * 64;
+                int r = 0;
+#pragma unroll
+                for (int step = 64; step >= 1; step >>= 1)
+                    if (r + step < nrows && rpre[r + step] <= w) r += step;
+                rowat[lane] = (unsigned char)r;
+            }
+        } else if (wave == 1) {    // own rows (centre z row of triples 1..re, the tile's own cells)
+            const int c = (lane < re) ? (int)rcnt[3 * (3 * (lane + 1) + 1) + 1] : 0;
+            int inc = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += v;
+            }
+            if (lane < re) qrow[lane + 1] = inc;
+            if (lane == 0) qrow[0] = 0;
+        }
+        __syncthreads();
+        const bool overflow0 = s_flag != 0;
+        WOL_STAMP(1);
+        // ---- phase 2: every staged water gets a thread (slot k: water tid + k * block of the tile's row-major
+        //      list; its row by binary search in rpre): all loads are issued together, then fine bin and rank
+        //      (returning LDS atomic).  The slots stay in registers for the placement pass. ----
+        constexpr int NS = (2 * WOL_ROWS_CAPP + WOL_ROWS_BLOCK - 1) / WOL_ROWS_BLOCK;
+        const int total_w = rpre[nrows];
+        int s_src[NS], s_info[NS];
+        float4 s_v[NS];
+        if (!overflow0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int w = tid + k * WOL_ROWS_BLOCK;
+                s_src[k] = -1;
+                if (w < total_w) {
+                    int r = rowat[w >> 6];           // rows are mostly longer than 64: zero to two steps
+                    while (rpre[r + 1] <= w) ++r;
+                    const int i = w - rpre[r];
+                    const int c0 = rcnt[3 * r], c1 = rcnt[3 * r + 1];
+                    const int piece = (i < c0) ? 0 : (i < c0 + c1) ? 1 : 2;
+                    s_src[k] = rsrc[3 * r + piece] + (i - (piece == 0 ? 0 : piece == 1 ? c0 : c0 + c1));
+                    s_info[k] = (r << 2) | piece;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (s_src[k] >= 0) s_v[k] = sp32[s_src[k]];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (s_src[k] < 0) continue;
+                const int r = s_info[k] >> 2, piece = s_info[k] & 3;
+                const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f));
+                const int sc = (piece == 0) ? 0 : (piece == 1) ? (int)s_v[k].w - x0 + 1 : sxe + 1;
+                const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(s_v[k].x * inv_wf));
+                const unsigned old = atomicAdd(&bins[t * nbw + (bin >> 1)], (bin & 1) ? 0x10000u : 1u);
+                const unsigned rank = (bin & 1) ? (old >> 16) : (old & 0xFFFFu);
+                if (rank > 1023u) s_flag = 1;
+                s_info[k] = (r << 20) | (bin << 10) | (int)(rank & 1023u);   // r < 96, bin < 256, rank < 1024
+            }
+        }
+        __syncthreads();
+        WOL_STAMP(2);
+        // ---- phase 2b: counts -> starts inside every triple (a wave per triple, four bins per lane) ----
+        for (int t = wave; t < ntrip; t += NW) {
+            unsigned* __restrict__ bt = bins + t * nbw;
+            const bool mine = 2 * lane < nbw;      // this lane's two words (bins 4*lane .. 4*lane+3) exist
+            const unsigned w0 = mine ? bt[2 * lane] : 0u, w1 = (2 * lane + 1 < nbw) ? bt[2 * lane + 1] : 0u;
+            int c[4] = {(int)(w0 & 0xFFFFu), (int)(w0 >> 16), (int)(w1 & 0xFFFFu), (int)(w1 >> 16)};
+            int s = 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { if (4 * lane + u >= nb) c[u] = 0; s += c[u]; }
+            int inc = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += v;
+            }
+            const int tot = __shfl(inc, 63, 64);
+            int run = inc - s, st[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { st[u] = (4 * lane + u < nb) ? run : tot; run += c[u]; }   // bin nb holds the total
+            if (mine) bt[2 * lane] = (unsigned)st[0] | ((unsigned)st[1] << 16);
+            if (2 * lane + 1 < nbw) bt[2 * lane + 1] = (unsigned)st[2] | ((unsigned)st[3] << 16);
+            if (lane == 63) ttot[t] = tot;
+        }
+        __syncthreads();
+        if (wave == 0) {           // triples start on even entries
+            const int len = (lane < ntrip) ? (ttot[lane] + 1) & ~1 : 0;
+            int inc = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += v;
+            }
+            if (lane < ntrip) {
+                tbase[lane] = inc - len;
+                if (ttot[lane] & 1) {      // complete the triple's last pair with a far-away dummy
+                    const int e = inc - len + ttot[lane];
+                    const int o = (e >> 1) * 4 + 1;
+                    recf[o] = 1.0e7f; recf[o + 2] = 1.0e7f; recg[o] = 1.0e7f;
+                    recg[o + 2] = __uint_as_float((unsigned)e << WOL_SLOT_BITS);
+                }
+            }
+            if (lane == ntrip - 1) tbase[ntrip] = inc;
+        }
+        __syncthreads();
+        const bool overflow = s_flag != 0;
+        const int total_e = tbase[ntrip];
+        WOL_STAMP(3);
+        const int dummy_p = (total_e >> 1) + WOL_ROWS_PADP - 2;
+        // ---- phase 3: every water to its place (from the registers of phase 2) ----
+        if (!overflow) {
+#if WOL_ROWS_RELOAD   // the coordinates are fetched again (L2-hot) instead of living in registers across the scans
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if (s_src[k] >= 0) s_v[k] = sp32[s_src[k]];
+#endif
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (s_src[k] < 0) continue;
+                const int r = s_info[k] >> 20, bin = (s_info[k] >> 10) & 1023, rank = s_info[k] & 1023;
+                const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f)), dzk = r - 3 * t;
+                const int sc = (int)((unsigned)bin / (unsigned)WOL_XSUB);
+                const int e = tbase[t] + (int)bins16[2 * t * nbw + bin] + rank;
+                const int o = (e >> 1) * 4 + (e & 1);
+                recf[o] = ((float)sc - xc) * fx + s_v[k].x;
+                recf[o + 2] = ((float)t - yc) * fy + s_v[k].y;
+                recg[o] = (float)(dzk - 1) * fz + s_v[k].z;
+                recg[o + 2] = __uint_as_float(((unsigned)e << WOL_SLOT_BITS) | (unsigned)s_src[k]);
+            }
+            if (tid < WOL_ROWS_PADP) {   // head-room pairs (incl. the dummy pair): nothing near
+                const int p = (total_e >> 1) + tid;
+                float4 far;
+                far.x = far.y = far.z = far.w = 1.0e7f;
+                rec[p] = far;
+                far.z = far.w = __int_as_float(0);
+                rec[p + WOL_ROWS_CAPP + WOL_ROWS_PADP] = far;
+            }
+        }
+        __syncthreads();
+        WOL_STAMP(4);
+        // ---- sweep: one lane per own water, three windows ----
+        const int nq = qrow[re];
+        for (int qb = wave * 64; qb < nq; qb += WOL_ROWS_BLOCK) {
+            // every lane of the wave stays in the sweep (the trip-count butterfly needs all 64): lanes past the
+            // tile's last water shadow that water with empty windows and store nothing
+            const bool live = qb + lrank < nq;
+            const int qi = live ? qb + lrank : nq - 1;
+            int j = 0;  // own row: largest j with qrow[j] <= qi (re <= 30)
+#pragma unroll
+            for (int step = 16; step >= 1; step >>= 1)
+                if (j + step < re && qrow[j + step] <= qi) j += step;
+            const int self_slot = rsrc[3 * (3 * (j + 1) + 1) + 1] + (qi - qrow[j]);
+            int4 prop;
+            prop.x = prop.y = prop.z = prop.w = 0;
+            int kd3 = -1;
+            if (!overflow) {
+                const float4 me = sp32[self_slot];
+                const int sc = (int)me.w - x0 + 1;
+                const int b = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(me.x * inv_wf));
+                const float mx = ((float)sc - xc) * fx + me.x, my = ((float)(j + 1) - yc) * fy + me.y, mz = me.z;
+                const wol_f2 xi = {mx, mx}, yi = {my, my}, zi = {mz, mz};
+                const unsigned tmaxbits = __float_as_uint(g.tmax);
+                unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    const int t = j + dt;
+                    const unsigned short* __restrict__ bt = bins16 + 2 * t * nbw;
+                    const int lo = tbase[t] + (int)bt[b - WOL_XSUB], hi = tbase[t] + (int)bt[b + WOL_XSUB + 1];
+                    const int pb = lo >> 1, pe = live ? (hi + 1) >> 1 : pb;
+#ifdef WOL_EXP_NO_SWEEP   // ablation build: timing only, results are wrong
+                    k0 ^= (unsigned)(pb + pe);
+#else
+                    wol_rows_span(reinterpret_cast<const char*>(rec), pb, pe - pb, dummy_p * 16, xi, yi, zi, tmaxbits,
+                                  k0, k1, k2, k3, k4);
+#endif
+                }
+                const unsigned d3 = k3 >> WOL_ID_BITS, d4 = k4 >> WOL_ID_BITS;
+                const unsigned sat = (1u << (32 - WOL_ID_BITS)) - 1u - (unsigned)g.row_eps_units;
+                if (k3 != 0xFFFFFFFFu && d3 < sat && d4 - d3 > 2u * (unsigned)g.row_eps_units) {
+                    const unsigned m = (1u << WOL_ID_BITS) - 1u, sm = (1u << WOL_SLOT_BITS) - 1u;
+                    auto slot_of = [&](unsigned key) -> int {
+                        const unsigned e = key & m;
+                        return (int)(__float_as_uint(recg[(e >> 1) * 4 + 2 + (e & 1)]) & sm);
+                    };
+                    prop.x = slot_of(k0); prop.y = slot_of(k1); prop.z = slot_of(k2); prop.w = slot_of(k3);
+                    kd3 = (int)d3 + 1;  // keys are d2 - 1
+                }
+            }
+            if (live) {
+                a.prop[frame_off + self_slot] = prop;
+                a.prop_key[frame_off + self_slot] = kd3;
+            }
+        }
+        WOL_STAMP(5);
+    }
+}
