@@ -127,6 +127,19 @@ int wol_willard_density_points(wol_ctx* ctx, const double* pos, int n, const dou
                                const double* box, double smoothlen, double* densvals,
                                double* densnorms);
 
+/* ---- "next" row f-3: radial distribution functions ----------------------------- */
+/* waterlib.f90:316-357 RadialDistSame (called per frame by orderParam_lib.rdfCalc, :624-630): g(r) of one
+ * set, pairs counted once, bins ((k-1)w, k w], normalised as the reference does (NPos * BulkDens *
+ * (4./3.) * pi * w^3 * (k^3 - (k-1)^3), single-precision 4./3., pi = 3.141592653589).  Host pointers. */
+int wol_radial_dist_same(wol_ctx* ctx, const double* pos, int n, double binwidth, int totbins,
+                         double bulkdens, const double* box, double* rdf);
+/* waterlib.f90:193-231 RadialDist: atoms of pos2 around atoms of pos1 (normalised by n1). */
+int wol_radial_dist(wol_ctx* ctx, const double* pos1, int n1, const double* pos2, int n2,
+                    double binwidth, int totbins, double bulkdens, const double* box, double* rdf);
+/* waterlib.f90:363-389 PairDistanceHistogram for Dim = 3: raw counts (as doubles), zero distances skipped. */
+int wol_pair_distance_histogram(wol_ctx* ctx, const double* pos1, int n1, const double* pos2, int n2,
+                                double binwidth, int totbins, const double* box, double* hist);
+
 /* ---- level 3: the tetOrderCalc frame loop (orderParam_lib.py:1458-1495) ------------------- */
 /* T frames of n waters each; water w of frame t is at frames + t*frame_stride + w*atom_stride
  * (strides in doubles).  boxes is host [T][3].  Per frame: q for every water (sub == pos branch),

@@ -602,3 +602,77 @@ void wolo_willard_density_points(const double* pos, int n, const double* pts, in
         for (int k = 0; k < 3; ++k) densnorms[3 * (size_t)i + k] = nv[k] / nn;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * radial distribution functions / pair-distance histograms.
+ * waterlib.f90:316-357 RadialDistSame (pairs i<j of one set), :193-231 RadialDist (every Pos2 x Pos1
+ * pair), :363-389 PairDistanceHistogram (Dim = 3 here; zero distances skipped).  All share
+ *   distVec = jPos - iPos;  distVec -= BoxL*anint(distVec*iBoxL);  dist = sqrt(sum(distVec**2));
+ *   nbin = ceiling(dist/binwidth);  counted when nbin <= totbins
+ * and the two g(r) routines normalise with single-precision (4./3.) and pi = 3.141592653589D0:
+ *   rdf(k) = counts(k) / (NPos * BulkDens * (4./3.) * pi * binwidth**3 * (k**3 - (k-1)**3)).
+ * A zero distance gives nbin = 0, which the reference writes out of bounds (counts(0)); it is skipped here.
+ * ------------------------------------------------------------------------------------------ */
+static inline long rdf_bin(const double a[3], const double b[3], const double box[3], const double ib[3], double binwidth) {
+    double v[3];
+    for (int k = 0; k < 3; ++k) {
+        const double t = b[k] - a[k];
+        v[k] = t - box[k] * round(t * ib[k]);
+    }
+    const double dist = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    return (long)ceil(dist / binwidth);
+}
+
+static void rdf_normalise(const int64_t* counts, int totbins, int npos, double bulkdens, double binwidth, double* rdf) {
+    const double pi = 3.141592653589;
+    const double fourthirds = (double)(4.f / 3.f);
+    for (int k = 1; k <= totbins; ++k) {
+        const int shell = k * k * k - (k - 1) * (k - 1) * (k - 1);   /* integer arithmetic, as the Fortran */
+        const double den = (double)npos * bulkdens * fourthirds * pi * (binwidth * binwidth * binwidth) * (double)shell;
+        rdf[k - 1] = (double)counts[k - 1] / den;
+    }
+}
+
+void wolo_pair_counts(const double* pos1, int n1, const double* pos2, int n2, int same, double binwidth, int totbins,
+                      const double box[3], int64_t* counts) {
+    double ib[3];
+    ibox_of(box, ib);
+    for (int k = 0; k < totbins; ++k) counts[k] = 0;
+    #pragma omp parallel
+    {
+        int64_t* loc = (int64_t*)calloc((size_t)totbins, sizeof(int64_t));
+        #pragma omp for schedule(dynamic, 16)
+        for (int i = 0; i < n2; ++i)
+            for (int j = same ? i + 1 : 0; j < n1; ++j) {
+                const long nb = rdf_bin(pos2 + 3 * (size_t)i, pos1 + 3 * (size_t)j, box, ib, binwidth);
+                if (nb >= 1 && nb <= totbins) loc[nb - 1] += 1;
+            }
+        #pragma omp critical
+        for (int k = 0; k < totbins; ++k) counts[k] += loc[k];
+        free(loc);
+    }
+}
+
+void wolo_radial_dist_same(const double* pos, int n, double binwidth, int totbins, double bulkdens, const double box[3],
+                           double* rdf) {
+    int64_t* c = (int64_t*)malloc(sizeof(int64_t) * (size_t)totbins);
+    wolo_pair_counts(pos, n, pos, n, 1, binwidth, totbins, box, c);
+    rdf_normalise(c, totbins, n, bulkdens, binwidth, rdf);
+    free(c);
+}
+
+void wolo_radial_dist(const double* pos1, int n1, const double* pos2, int n2, double binwidth, int totbins,
+                      double bulkdens, const double box[3], double* rdf) {
+    int64_t* c = (int64_t*)malloc(sizeof(int64_t) * (size_t)totbins);
+    wolo_pair_counts(pos1, n1, pos2, n2, 0, binwidth, totbins, box, c);
+    rdf_normalise(c, totbins, n1, bulkdens, binwidth, rdf);
+    free(c);
+}
+
+void wolo_pair_distance_histogram(const double* pos1, int n1, const double* pos2, int n2, double binwidth, int totbins,
+                                  const double box[3], double* hist) {
+    int64_t* c = (int64_t*)malloc(sizeof(int64_t) * (size_t)totbins);
+    wolo_pair_counts(pos2, n2, pos1, n1, 0, binwidth, totbins, box, c);   /* counts are symmetric in the two sets */
+    for (int k = 0; k < totbins; ++k) hist[k] = (double)c[k];
+    free(c);
+}

@@ -205,3 +205,28 @@ def willarddensityfield(pos, gridx, gridy, gridz, boxl, smoothlen):
     dv, dn = willarddensitypoints(pos, pts, boxl, smoothlen)
     return (np.asfortranarray(dv.reshape(len(gx), len(gy), len(gz))),
             np.asfortranarray(dn.reshape(len(gx), len(gy), len(gz), 3)))
+
+
+# ---- radial distribution functions -----------------------------------------
+def radialdistsame(pos, binwidth, totbins, bulkdens, boxl):
+    """waterlib.radialdistsame -> rdf[totbins]"""
+    pos = _d(pos); box = _box(boxl); rdf = np.empty(int(totbins))
+    lib().wolo_radial_dist_same(_p(pos), C.c_int(len(pos)), C.c_double(binwidth), C.c_int(int(totbins)),
+                                C.c_double(bulkdens), _p(box), _p(rdf))
+    return rdf
+
+
+def radialdist(pos1, pos2, binwidth, totbins, bulkdens, boxl):
+    """waterlib.radialdist -> rdf[totbins] (atoms of pos2 around atoms of pos1)"""
+    p1 = _d(pos1); p2 = _d(pos2); box = _box(boxl); rdf = np.empty(int(totbins))
+    lib().wolo_radial_dist(_p(p1), C.c_int(len(p1)), _p(p2), C.c_int(len(p2)), C.c_double(binwidth),
+                           C.c_int(int(totbins)), C.c_double(bulkdens), _p(box), _p(rdf))
+    return rdf
+
+
+def pairdistancehistogram(pos1, pos2, binwidth, totbins, boxl):
+    """waterlib.pairdistancehistogram (Dim = 3) -> hist[totbins]"""
+    p1 = _d(pos1); p2 = _d(pos2); box = _box(boxl); h = np.empty(int(totbins))
+    lib().wolo_pair_distance_histogram(_p(p1), C.c_int(len(p1)), _p(p2), C.c_int(len(p2)), C.c_double(binwidth),
+                                       C.c_int(int(totbins)), _p(box), _p(h))
+    return h

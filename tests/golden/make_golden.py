@@ -185,6 +185,19 @@ def main():
                         smoothlen=2.4, densvals=dv, densnorms=dn, pts=pts, pts_densvals=pv, pts_densnorms=pn)
     print("willard_slab700    max density %.4f, grid points without water in range: %d" % (dv.max(), int(np.isnan(dn[..., 0]).sum())))
 
+    # (12) SURVEY 8f row f-3: radial distribution functions (waterlib.f90:193-231, 316-389) as rdfCalc calls them
+    xyzR, boxesR = synth.water_frames(700, 1, seed=31)
+    posR, boxR = xyzR[0], boxesR[0]
+    solR = np.random.default_rng(5).random((25, 3)) * boxR
+    np.savez_compressed(os.path.join(OUT, "rdf700.npz"), pos=posR, box=boxR, sol=solR, binwidth=0.1, totbins=150,
+                        rdf_same=wl.radialdistsame(posR, 0.1, 150, 1.0, boxR),
+                        rdf_sol_wat=wl.radialdist(solR, posR, 0.1, 150, 0.0334, boxR),
+                        rdf_sol_sol=wl.radialdistsame(solR, 0.1, 150, 1.0, boxR),
+                        hist_sol_wat=wl.pairdistancehistogram(solR, posR, 0.25, 60, boxR),
+                        hist_wat_wat=wl.pairdistancehistogram(posR, posR, 0.05, 300, boxR),
+                        rdf_same_nonperiodic_z=wl.radialdistsame(posR, 0.1, 150, 1.0, boxR * np.array([1, 1, -1.0])))
+    print("rdf700             first-shell peak g = %.3f (bulkdens 1 -> local density)" % wl.radialdistsame(posR, 0.1, 150, 1.0, boxR)[:40].max())
+
 
 if __name__ == "__main__":
     main()

@@ -400,3 +400,67 @@ def test_willard_edge_cases():
     dens, norms, spans, spacing = sl.densityField(heavy, xyz[0], boxes[0][None, :])
     assert dens.shape == (80, 80, 80) and norms.shape == (80, 80, 80, 3) and len(spans) == 3
     assert dens.max() > 0.02 and dens.min() >= 0.0
+
+
+# ---- radial distribution functions ------------------------------------------------
+def test_rdf_golden():
+    """bit-exact: integer pair counts per bin and the reference's normalisation arithmetic"""
+    from waterorderlib_amd import waterlib as wl
+    g = golden("rdf700")
+    pos, box, sol = g["pos"], g["box"], g["sol"]
+    assert np.array_equal(wl.radialdistsame(pos, 0.1, 150, 1.0, box), g["rdf_same"])
+    assert np.array_equal(wl.radialdist(sol, pos, 0.1, 150, 0.0334, box), g["rdf_sol_wat"])
+    assert np.array_equal(wl.radialdistsame(sol, 0.1, 150, 1.0, box[None, :]), g["rdf_sol_sol"])
+    assert np.array_equal(wl.pairdistancehistogram(sol, pos, 0.25, 60, box), g["hist_sol_wat"])
+    assert np.array_equal(wl.pairdistancehistogram(pos, pos, 0.05, 300, box), g["hist_wat_wat"])
+    assert np.array_equal(wl.radialdistsame(pos, 0.1, 150, 1.0, box * np.array([1, 1, -1.0])), g["rdf_same_nonperiodic_z"])
+
+
+def test_rdf_vs_oracle_and_properties(oracle):
+    from waterorderlib_amd import synth, waterlib as wl
+    oracle.set_threads(8)
+    xyz, boxes = synth.water_frames(6000, 1, seed=61, box=np.array([52.0, 61.5, 56.1]))
+    pos, box = xyz[0], boxes[0]
+    rng = np.random.default_rng(62)
+    unwrapped = pos + rng.integers(-2, 3, size=pos.shape) * box
+    sol = rng.random((300, 3)) * box * 1.3 - 4.0
+    assert np.array_equal(wl.radialdistsame(unwrapped, 0.1, 150, 1.0, box), oracle.radialdistsame(unwrapped, 0.1, 150, 1.0, box))
+    assert np.array_equal(wl.radialdist(sol, pos, 0.1, 150, 0.0334, box), oracle.radialdist(sol, pos, 0.1, 150, 0.0334, box))
+    assert np.array_equal(wl.radialdist(pos, sol, 0.07, 111, 2.0, box), oracle.radialdist(pos, sol, 0.07, 111, 2.0, box))
+    # range beyond half the box (every cell visited once, minimum image decides) and a tiny box
+    assert np.array_equal(wl.pairdistancehistogram(pos[:1500], pos, 0.4, 120, box), oracle.pairdistancehistogram(pos[:1500], pos, 0.4, 120, box))
+    small, sbox = pos[:80] * 0.2, np.array([11.0, 12.5, 10.4])
+    assert np.array_equal(wl.radialdistsame(small, 0.1, 150, 1.0, sbox), oracle.radialdistsame(small, 0.1, 150, 1.0, sbox))
+    # a histogram that spans the whole box counts every ordered pair once; g(r) of an ideal gas is flat
+    h = wl.pairdistancehistogram(pos, pos, 0.5, 120, box)
+    assert h.sum() == len(pos) * (len(pos) - 1)
+    gas, gbox = synth.ideal_gas(20000, seed=63)
+    gr = wl.radialdistsame(gas, 0.5, 20, 20000 / np.prod(gbox), gbox)
+    assert np.all(np.abs(2.0 * gr[4:] - 1.0) < 0.05)       # pairs counted once -> g/2
+    # edge cases: empty sets, coincident points (zero distance is not counted)
+    assert np.all(np.isnan(wl.radialdistsame(np.zeros((0, 3)), 0.1, 10, 1.0, box)))   # 0 / (0 * ...), as the reference
+    assert np.all(wl.radialdist(sol, np.zeros((0, 3)), 0.1, 10, 1.0, box) == 0)
+    two = np.array([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0], [1.0, 1.0, 2.0]])
+    assert wl.pairdistancehistogram(two, two, 0.5, 4, box).tolist() == [0.0, 4.0, 0.0, 0.0]
+    with pytest.raises(RuntimeError):
+        wl.radialdistsame(pos, -0.1, 10, 1.0, box)
+
+
+def test_rdf_driver(tmp_path, monkeypatch):
+    """rdfCalc (orderParam_lib.py:575-727) on an array-backed trajectory with solute atoms; its g(r) arrays equal
+    the per-frame library calls averaged the same way"""
+    from waterorderlib_amd import synth, orderParam_lib as opl, waterlib as wl
+    from waterorderlib_amd.TrajObject import TrajObject
+    monkeypatch.chdir(tmp_path)
+    xyz, boxes = synth.water_frames(900, 10, seed=71)
+    sol = np.random.default_rng(72).random((10, 12, 3)) * boxes[:, None, :]
+    allxyz = np.concatenate([xyz, sol], axis=1)
+    obj = TrajObject(allxyz, boxes, lenWat=1, nWaters=900, solInds=np.arange(900, 912))
+    n1_ow, n1_sol, tpar = opl.rdfCalc(obj, binwidth=0.1, totbins=150)
+    # (two noisy frames per chunk: the first relative minimum comes early; only sanity is asserted on the integrals)
+    assert 0.0 < n1_ow[0] < 8.0 and np.isfinite(n1_sol[0]) and np.isfinite(tpar[0])
+    rd = opl.rdfCalc.last_rdfs["OwOw"]
+    assert rd.shape == (5, 150)
+    expect = (wl.radialdistsame(xyz[0], 0.1, 150, 1.0, boxes[0]) + wl.radialdistsame(xyz[1], 0.1, 150, 1.0, boxes[1])) / 2.0
+    assert np.array_equal(rd[0], expect)
+    assert np.loadtxt("rdf.txt").shape == (150, 7) and np.loadtxt("coord.txt").shape == (148, 7)

@@ -105,3 +105,19 @@ def test_willard_density_field(oracle):
     assert np.array_equal(dv, g["densvals"]) and np.array_equal(dn, g["densnorms"], equal_nan=True)
     pv, pn = oracle.willarddensitypoints(g["pos"], g["pts"], g["box"], float(g["smoothlen"]))
     assert np.array_equal(pv, g["pts_densvals"]) and np.array_equal(pn, g["pts_densnorms"], equal_nan=True)
+
+
+def test_radial_distribution_functions(oracle):
+    """SURVEY 8f row f-3 (waterlib.f90:193-231, 316-389): counts, bin rule and the single-precision 4./3. /
+    truncated-pi normalisation reproduce the reference bit for bit"""
+    g = golden("rdf700")
+    pos, box, sol = g["pos"], g["box"], g["sol"]
+    assert np.array_equal(oracle.radialdistsame(pos, 0.1, 150, 1.0, box), g["rdf_same"])
+    assert np.array_equal(oracle.radialdist(sol, pos, 0.1, 150, 0.0334, box), g["rdf_sol_wat"])
+    assert np.array_equal(oracle.radialdistsame(sol, 0.1, 150, 1.0, box), g["rdf_sol_sol"])
+    assert np.array_equal(oracle.pairdistancehistogram(sol, pos, 0.25, 60, box), g["hist_sol_wat"])
+    assert np.array_equal(oracle.pairdistancehistogram(pos, pos, 0.05, 300, box), g["hist_wat_wat"])
+    assert np.array_equal(oracle.radialdistsame(pos, 0.1, 150, 1.0, box * np.array([1, 1, -1.0])), g["rdf_same_nonperiodic_z"])
+    # every pair lands in exactly one bin when the range covers the box diagonal
+    h = oracle.pairdistancehistogram(pos, pos, 0.5, 100, box)
+    assert h.sum() == len(pos) * (len(pos) - 1)

@@ -40,7 +40,8 @@ class TrajObject:
     """TrajObject(xyz[T,natoms,3], boxes[T,3], lenWat, stride=1): waters are the first
     nWaters*lenWat atoms, oxygen first in each water (AMBER WAT residue order O,H1,H2[,EPW])."""
 
-    def __init__(self, xyz, boxes, lenWat=1, nWaters=None, stride=1):
+    def __init__(self, xyz, boxes, lenWat=1, nWaters=None, stride=1, solInds=None):
+        self.solInds = None if solInds is None else np.asarray(solInds, dtype=int)
         self.traj = ArrayTrajectory(xyz, boxes, stride)
         self.top = None
         self.stride = stride
@@ -56,5 +57,7 @@ class TrajObject:
         return watInds, watHInds, self.lenWat
 
     def getSolInds(self):
+        """(solInds, solHInds, solCInds, solNInds, solOInds, solSInds) as TrajObject.py:54-78; only the heavy-atom
+        list (given at construction) is known to an array-backed trajectory"""
         e = np.array([], dtype=int)
-        return e, e, e, e, e, e
+        return (e if self.solInds is None else self.solInds), e, e, e, e, e

@@ -20,7 +20,8 @@ SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy",
            "wol_ctx_synchronize", "wol_ctx_set_option", "wol_ctx_kernel_time", "wol_ctx_get_counter", "wol_reimage",
            "wol_near_neighbors", "wol_all_near_neighbors", "wol_tetra_cos_ang", "wol_lsi_dists",
            "wol_q_frame", "wol_cos_angs", "wol_lsi_frame", "wol_q_traj", "wol_q_traj_f32",
-           "wol_willard_density_field", "wol_willard_density_points"]
+           "wol_willard_density_field", "wol_willard_density_points",
+           "wol_radial_dist_same", "wol_radial_dist", "wol_pair_distance_histogram"]
 
 _lib = None
 
@@ -78,6 +79,9 @@ def load():
     L.wol_willard_density_field.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp, C.c_int, _vp,
                                             C.c_double, _vp, _vp]
     L.wol_willard_density_points.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, _vp, C.c_double, _vp, _vp]
+    L.wol_radial_dist_same.argtypes = [_vp, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp]
+    L.wol_radial_dist.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp]
+    L.wol_pair_distance_histogram.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]
     traj = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, _vp,
             C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]
     L.wol_q_traj.argtypes = traj

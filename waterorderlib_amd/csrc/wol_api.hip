@@ -1186,6 +1186,75 @@ int wol_willard_density_points(wol_ctx* c, const double* pos, int n, const doubl
     return willard_impl(c, pos, n, pts, npts, nullptr, 0, nullptr, 0, nullptr, 0, box, smoothlen, densvals, densnorms);
 }
 
+// ---- radial distribution functions --------------------------------------------
+// counts of pair distances per bin: candidates = pos2 (cell-sorted), queries = pos1 (null: pos2 itself, pairs once)
+static int pair_counts_impl(wol_ctx* c, const double* pos1, int n1, const double* pos2, int n2, double binwidth,
+                            int totbins, const double* box, std::vector<long long>* counts) {
+    WOL_TRY(check_ctx(c));
+    if (!pos2 || !box || n1 < 0 || n2 < 0) return fail(WOL_ERR_INVALID, "rdf: bad argument");
+    if (!(binwidth > 0.0) || totbins <= 0 || totbins > 12000) return fail(WOL_ERR_INVALID, "rdf: need binwidth > 0 and 0 < totbins <= 12000");
+    counts->assign((size_t)totbins, 0);
+    const int nq = pos1 ? n1 : n2;
+    if (n2 == 0 || nq == 0) return WOL_OK;
+    ShellArgs sa;
+    WOL_TRY(shell_setup(c, pos2, n2, pos1, n1, box, binwidth * (double)totbins, &sa));
+    WOL_TRY(c->hist_stage.ensure(sizeof(unsigned long long) * (size_t)totbins));
+    HIP_TRY(hipMemsetAsync(c->hist_stage.p, 0, sizeof(unsigned long long) * (size_t)totbins, c->stream));
+    const size_t lds = sizeof(int) * (size_t)totbins;
+    int grid = 0;
+    WOL_TRY(resident_grid(c, k_pair_hist, WOL_BLOCK, lds, (nq + WOL_BLOCK - 1) / WOL_BLOCK, &grid));
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+    hipLaunchKernelGGL(k_pair_hist, dim3(grid), dim3(WOL_BLOCK), lds, c->stream, sa, pos1 ? 0 : 1, binwidth, totbins,
+                       c->hist_stage.as<unsigned long long>());
+    if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    HIP_TRY(hipMemcpyAsync(counts->data(), c->hist_stage.p, sizeof(long long) * (size_t)totbins, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+// rdf(k) = counts(k) / (NPos * BulkDens * (4./3.) * pi * binwidth**3 * (k**3 - (k-1)**3)) with the reference's
+// single-precision 4./3., truncated pi and integer k**3 (waterlib.f90:227-229, 353-355)
+static void rdf_normalise(const std::vector<long long>& counts, int npos, double bulkdens, double binwidth, double* rdf) {
+    const double pi = 3.141592653589;
+    const double fourthirds = (double)(4.f / 3.f);
+    for (int k = 1; k <= (int)counts.size(); ++k) {
+        const int shell = k * k * k - (k - 1) * (k - 1) * (k - 1);
+        const double den = (double)npos * bulkdens * fourthirds * pi * (binwidth * binwidth * binwidth) * (double)shell;
+        rdf[k - 1] = (double)counts[(size_t)k - 1] / den;
+    }
+}
+
+int wol_radial_dist_same(wol_ctx* c, const double* pos, int n, double binwidth, int totbins, double bulkdens,
+                         const double* box, double* rdf) {
+    if (!rdf) return fail(WOL_ERR_INVALID, "rdf: output must not be NULL");
+    if (totbins > 1290) return fail(WOL_ERR_INVALID, "rdf: totbins > 1290 overflows the reference's integer k**3");
+    std::vector<long long> counts;
+    WOL_TRY(pair_counts_impl(c, nullptr, 0, pos, n, binwidth, totbins, box, &counts));
+    rdf_normalise(counts, n, bulkdens, binwidth, rdf);
+    return WOL_OK;
+}
+
+int wol_radial_dist(wol_ctx* c, const double* pos1, int n1, const double* pos2, int n2, double binwidth, int totbins,
+                    double bulkdens, const double* box, double* rdf) {
+    if (!rdf || !pos1) return fail(WOL_ERR_INVALID, "rdf: pos1 / output must not be NULL");
+    if (totbins > 1290) return fail(WOL_ERR_INVALID, "rdf: totbins > 1290 overflows the reference's integer k**3");
+    std::vector<long long> counts;
+    WOL_TRY(pair_counts_impl(c, pos1, n1, pos2, n2, binwidth, totbins, box, &counts));
+    rdf_normalise(counts, n1, bulkdens, binwidth, rdf);
+    return WOL_OK;
+}
+
+int wol_pair_distance_histogram(wol_ctx* c, const double* pos1, int n1, const double* pos2, int n2, double binwidth,
+                                int totbins, const double* box, double* hist) {
+    if (!hist || !pos1) return fail(WOL_ERR_INVALID, "pair histogram: pos1 / output must not be NULL");
+    std::vector<long long> counts;
+    WOL_TRY(pair_counts_impl(c, pos1, n1, pos2, n2, binwidth, totbins, box, &counts));
+    for (int k = 0; k < totbins; ++k) hist[k] = (double)counts[(size_t)k];
+    return WOL_OK;
+}
+
 // ---- level 3 ------------------------------------------------------------------------------
 int wol_q_traj(wol_ctx* c, const double* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
                const double* boxes, double lowcut, double highcut, double* mean, double* var, int64_t* qhist,

@@ -298,3 +298,32 @@ k_willard(ShellArgs a, WillardArgs w) {
         w.densnorms[3 * id] = n0 / nn; w.densnorms[3 * id + 1] = n1 / nn; w.densnorms[3 * id + 2] = n2 / nn;
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// pair-distance histograms behind RadialDistSame / RadialDist / PairDistanceHistogram
+// (waterlib.f90:316-357, 193-231, 363-389; caller orderParam_lib.rdfCalc :575-727).  One lane per query
+// walks the cells within totbins*binwidth (the reference loops over all pairs); dist = sqrt((x^2+y^2)+z^2)
+// of the minimum-image vector and nbin = ceiling(dist/binwidth) as the reference; integer counts in an
+// LDS histogram, flushed with 64-bit atomics.  `same`: the queries are the candidates themselves and each
+// unordered pair is counted once (slot order instead of the reference's index order: the same pair set).
+// Zero distances are skipped (PairDistanceHistogram does; in the other two the reference writes counts(0)).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long long* __restrict__ hist) {
+    extern __shared__ int lds_hist[];
+    wol_hist_zero(lds_hist, totbins);
+    __syncthreads();
+    for (int q = blockIdx.x * WOL_BLOCK + threadIdx.x; q < a.ns; q += gridDim.x * WOL_BLOCK) {
+        double c[3];
+        int row;
+        wol_shell_query(a, q, c, &row);
+        wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
+            if (same && slot <= q) return;
+            if (!(d2 > 0.0)) return;
+            const int bin = wol_dist_bin(sqrt(d2), binwidth, totbins);
+            if (bin >= 0) atomicAdd(&lds_hist[bin], 1);
+        });
+    }
+    __syncthreads();
+    wol_hist_flush(lds_hist, totbins, hist);
+}

@@ -194,3 +194,73 @@ def lsiCalc(topFile, trajFile=None, subInds=None, nPops=0, solResName='(!:WAT)',
                        header='lsiVal [A^2]    frequency', fmt="%.3e")
     lsiCalc.last_values = pooled
     return _mean_ci(avgLSI, rng), _mean_ci(varLSI, rng)
+
+
+def rdfCalc(topFile, trajFile=None, solResName='(!:WAT)', watResName='(:WAT)', binwidth=0.1, totbins=150, stride=1,
+            write=True):
+    """orderParam_lib.py:575-727: Ow-Ow, solute-Ow and solute-solute radial distribution functions (wl.radialdistsame /
+    wl.radialdist per frame with bulkdens = 1, averaged over five trajectory chunks), running coordination numbers by
+    Simpson integration, first-minimum coordination n1 and the translational parameter; writes rdf.txt and coord.txt.
+
+    Returns ([n1_OwOw, se], [n1_SolOw, se], [tParam, se]) with solute atoms, else (n1_OwOw, tParam) -- the reference
+    returns its frame counter `t` in that branch (:727), an obvious slip.  scipy's `simps` of the reference is
+    today's `simpson`, whose even-sample rule changed in scipy 1.11: the integrals are parity-unpinned, the g(r)
+    arrays (rdfCalc.last_rdfs) are what the parity tests check."""
+    from scipy.integrate import simpson
+    from scipy.signal import argrelmin
+    from . import waterlib as wl
+    obj = _as_traj_object(topFile, trajFile, stride, solResName, watResName)
+    xyz, boxes, watInds = _frames_of(obj)
+    solInds = np.asarray(obj.getSolInds()[0], dtype=int)
+    has_sol = len(solInds) > 0
+    nChunks = 5
+    chunkSize = int(len(xyz) / nChunks)
+    if chunkSize < 1:
+        raise ValueError("rdfCalc needs at least %d frames (five chunks, as the reference)" % nChunks)
+    dist = np.linspace(0, (totbins - 1) * binwidth, totbins) + binwidth
+    tot = {k: [] for k in ("OwOw", "SolOw", "SolSol")}
+    totc = {k: [] for k in ("OwOw", "SolOw", "SolSol")}
+    tot_n1_OwOw, tot_n1_SolOw, tot_tParam = [], [], []
+    for c in range(nChunks):
+        rdf = {k: np.zeros(totbins) for k in tot}
+        t = 0
+        for t, f in enumerate(range(int(c * chunkSize), int((c + 1) * chunkSize))):
+            thisWat = np.ascontiguousarray(xyz[f][watInds])
+            rdf["OwOw"] = rdf["OwOw"] + wl.radialdistsame(thisWat, binwidth, totbins, 1.0, boxes[f])
+            if has_sol:
+                thisSol = np.ascontiguousarray(xyz[f][solInds])
+                rdf["SolSol"] = rdf["SolSol"] + wl.radialdistsame(thisSol, binwidth, totbins, 1.0, boxes[f])
+                rdf["SolOw"] = rdf["SolOw"] + wl.radialdist(thisSol, thisWat, binwidth, totbins, 1.0, boxes[f])
+        coord = {k: np.zeros(len(dist) - 2) for k in tot}
+        for k in tot:
+            rdf[k] = rdf[k] / (1.0 + t)
+            tot[k].append(rdf[k])
+        for j in range(2, len(dist)):
+            coord["OwOw"][j - 2] = 8.0 * np.pi * simpson(rdf["OwOw"][:j] * dist[:j] ** 2.0, x=dist[:j])
+            if has_sol:
+                coord["SolOw"][j - 2] = 4.0 * np.pi * simpson(rdf["SolOw"][:j] * dist[:j] ** 2.0, x=dist[:j])
+                coord["SolSol"][j - 2] = 8.0 * np.pi * simpson(rdf["SolSol"][:j] * dist[:j] ** 2.0, x=dist[:j])
+        for k in tot:
+            totc[k].append(coord[k])
+        if has_sol:
+            tot_n1_SolOw.append(coord["SolOw"][argrelmin(rdf["SolOw"])[0][0] - 2])
+        m0 = argrelmin(rdf["OwOw"])[0][0]
+        tot_n1_OwOw.append(coord["OwOw"][m0 - 2])
+        tot_tParam.append(simpson(rdf["OwOw"][:m0] / rdf["OwOw"][-1], x=dist[:m0]) / dist[m0])
+    arr = {k: np.array(v) for k, v in tot.items()}
+    arrc = {k: np.array(v) for k, v in totc.items()}
+    se = lambda a: np.std(a, axis=0, ddof=1) / np.sqrt(nChunks - 1)
+    rdfCalc.last_rdfs = arr
+    if write:   # the reference writes the LAST chunk's curves next to the across-chunk standard errors (:703-716)
+        np.savetxt('rdf.txt', np.stack([dist, arr["OwOw"][-1], se(arr["OwOw"]), arr["SolSol"][-1], se(arr["SolSol"]),
+                                        arr["SolOw"][-1], se(arr["SolOw"])], axis=1),
+                   header='pair distance (A)     Ow-Ow rdf     err     Sol-Sol rdf     err     Sol-Ow rdf     err', fmt="%.3e")
+        np.savetxt('coord.txt', np.stack([dist[2:], arrc["OwOw"][-1], se(arrc["OwOw"]), arrc["SolSol"][-1],
+                                          se(arrc["SolSol"]), arrc["SolOw"][-1], se(arrc["SolOw"])], axis=1),
+                   header='pair distance (A)     Ow-Ow n1     err     Sol-Sol n1     err     Sol-Ow n1     err', fmt="%.3e")
+    n1_OwOw, tParam = np.mean(tot_n1_OwOw), np.mean(tot_tParam)
+    if has_sol:
+        return ([n1_OwOw, np.std(np.array(tot_n1_OwOw), ddof=1) / np.sqrt(nChunks - 1)],
+                [np.mean(tot_n1_SolOw), np.std(np.array(tot_n1_SolOw), ddof=1) / np.sqrt(nChunks - 1)],
+                [tParam, np.std(np.array(tot_tParam), ddof=1) / np.sqrt(nChunks - 1)])
+    return n1_OwOw, tParam

@@ -113,3 +113,32 @@ def willarddensitypoints(pos, denspts, boxl, smoothlen, npos=None, npts=None):
                                                       _lib.ptr(pts), len(pts), _lib.ptr(box), float(smoothlen),
                                                       _lib.ptr(dv), _lib.ptr(dn)))
     return dv, np.asfortranarray(dn)
+
+
+def radialdistsame(pos, binwidth, totbins, bulkdens, boxl, npos=None):
+    """rdf = radialdistsame(pos,binwidth,totbins,bulkdens,boxl,[npos]) -- waterlib.f90:316-357"""
+    pos = _pos(pos, "pos"); box = _lib.box3(boxl)
+    rdf = np.empty(int(totbins), dtype=np.float64)
+    _lib.check(_lib.load().wol_radial_dist_same(_lib.default_context().handle, _lib.ptr(pos), len(pos), float(binwidth),
+                                                int(totbins), float(bulkdens), _lib.ptr(box), _lib.ptr(rdf)))
+    return rdf
+
+
+def radialdist(pos1, pos2, binwidth, totbins, bulkdens, boxl, npos1=None, npos2=None):
+    """rdf = radialdist(pos1,pos2,binwidth,totbins,bulkdens,boxl,[npos1,npos2]) -- waterlib.f90:193-231"""
+    p1 = _pos(pos1, "pos1"); p2 = _pos(pos2, "pos2"); box = _lib.box3(boxl)
+    rdf = np.empty(int(totbins), dtype=np.float64)
+    _lib.check(_lib.load().wol_radial_dist(_lib.default_context().handle, _lib.ptr(p1), len(p1), _lib.ptr(p2), len(p2),
+                                           float(binwidth), int(totbins), float(bulkdens), _lib.ptr(box), _lib.ptr(rdf)))
+    return rdf
+
+
+def pairdistancehistogram(pos1, pos2, binwidth, totbins, boxl, npos1=None, npos2=None, dim=None):
+    """hist = pairdistancehistogram(pos1,pos2,binwidth,totbins,boxl,[npos1,npos2,dim]) -- waterlib.f90:363-389
+    (three-dimensional positions only)"""
+    p1 = _pos(pos1, "pos1"); p2 = _pos(pos2, "pos2"); box = _lib.box3(boxl)
+    hist = np.empty(int(totbins), dtype=np.float64)
+    _lib.check(_lib.load().wol_pair_distance_histogram(_lib.default_context().handle, _lib.ptr(p1), len(p1), _lib.ptr(p2),
+                                                       len(p2), float(binwidth), int(totbins), _lib.ptr(box),
+                                                       _lib.ptr(hist)))
+    return hist
