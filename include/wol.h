@@ -127,6 +127,17 @@ int wol_willard_density_points(wol_ctx* ctx, const double* pos, int n, const dou
                                const double* box, double smoothlen, double* densvals,
                                double* densnorms);
 
+/* ---- "next" row f-2: water orientation -------------------------------------------- */
+/* waterlib.f90:973-1011 watOrient (called by water_properties.waterOrientation / waterOrientationBinZ,
+ * :578-638): per water the angle (degrees) between a reference direction and (i) its dipole = sum of
+ * the two minimum-imaged O-H vectors, (ii) the normal OH1 x OH2 of its molecular plane.  opos [n][3],
+ * hpos [2n][3] (hydrogens of water i in rows 2i, 2i+1), host pointers. */
+int wol_wat_orient(wol_ctx* ctx, const double* opos, const double* hpos, int n, const double* refvec,
+                   const double* box, double* angdip, double* angplane);
+/* waterlib.f90:1019-1044 watOHvec: unit dipole vectors, row-major [n][3]. */
+int wol_wat_oh_vec(wol_ctx* ctx, const double* opos, const double* hpos, int n, const double* box,
+                   double* normdip);
+
 /* ---- "next" row f-3: radial distribution functions ----------------------------- */
 /* waterlib.f90:316-357 RadialDistSame (called per frame by orderParam_lib.rdfCalc, :624-630): g(r) of one
  * set, pairs counted once, bins ((k-1)w, k w], normalised as the reference does (NPos * BulkDens *

@@ -676,3 +676,63 @@ void wolo_pair_distance_histogram(const double* pos1, int n1, const double* pos2
     for (int k = 0; k < totbins; ++k) hist[k] = (double)c[k];
     free(c);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * water orientation.  waterlib.f90:954-965 AngBetween, :973-1011 watOrient (angle of the
+ * dipole = sum of the two imaged O-H vectors, and of the molecular-plane normal = OH1 x OH2, to a reference
+ * direction, degrees), :1019-1044 watOHvec (unit dipole).  hpos holds the two hydrogens of water i in rows
+ * 2i, 2i+1.
+ * ------------------------------------------------------------------------------------------ */
+static double ang_between(const double a[3], const double b[3]) {
+    const double pi = WOLO_PI;
+    const double DegPerRad = 180.0 / pi;
+    double phi = fmin(1.0, fmax(-1.0, (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]));
+    phi = acos(phi);
+    double r = fmod(phi + pi, pi * 2.0) - pi;
+    if (r < -pi) r = r + pi * 2.0;
+    return r * DegPerRad;
+}
+
+static void oh_vectors(const double* o, const double* h1, const double* h2, const double box[3], const double ib[3],
+                       double v1[3], double v2[3], double dip[3]) {
+    for (int k = 0; k < 3; ++k) {
+        double t = h1[k] - o[k];
+        v1[k] = t - box[k] * round(t * ib[k]);
+        t = h2[k] - o[k];
+        v2[k] = t - box[k] * round(t * ib[k]);
+        t = v1[k] + v2[k];
+        dip[k] = t - box[k] * round(t * ib[k]);
+    }
+}
+
+void wolo_wat_orient(const double* opos, const double* hpos, int n, const double refvec[3], const double box[3],
+                     double* angdip, double* angplane) {
+    double ib[3], ref[3];
+    ibox_of(box, ib);
+    const double rn = sqrt((refvec[0] * refvec[0] + refvec[1] * refvec[1]) + refvec[2] * refvec[2]);
+    for (int k = 0; k < 3; ++k) ref[k] = refvec[k] / rn;
+    for (int i = 0; i < n; ++i) {
+        double v1[3], v2[3], dip[3], pl[3], u[3];
+        oh_vectors(opos + 3 * (size_t)i, hpos + 6 * (size_t)i, hpos + 6 * (size_t)i + 3, box, ib, v1, v2, dip);
+        const double nd = sqrt(sumsq3(dip));
+        for (int k = 0; k < 3; ++k) u[k] = dip[k] / nd;
+        angdip[i] = ang_between(u, ref);
+        pl[0] = v1[1] * v2[2] - v1[2] * v2[1];
+        pl[1] = v1[2] * v2[0] - v1[0] * v2[2];
+        pl[2] = v1[0] * v2[1] - v1[1] * v2[0];
+        const double np_ = sqrt(sumsq3(pl));
+        for (int k = 0; k < 3; ++k) u[k] = pl[k] / np_;
+        angplane[i] = ang_between(u, ref);
+    }
+}
+
+void wolo_wat_oh_vec(const double* opos, const double* hpos, int n, const double box[3], double* normdip) {
+    double ib[3];
+    ibox_of(box, ib);
+    for (int i = 0; i < n; ++i) {
+        double v1[3], v2[3], dip[3];
+        oh_vectors(opos + 3 * (size_t)i, hpos + 6 * (size_t)i, hpos + 6 * (size_t)i + 3, box, ib, v1, v2, dip);
+        const double nd = sqrt(sumsq3(dip));
+        for (int k = 0; k < 3; ++k) normdip[3 * (size_t)i + k] = dip[k] / nd;
+    }
+}

@@ -230,3 +230,24 @@ def pairdistancehistogram(pos1, pos2, binwidth, totbins, boxl):
     lib().wolo_pair_distance_histogram(_p(p1), C.c_int(len(p1)), _p(p2), C.c_int(len(p2)), C.c_double(binwidth),
                                        C.c_int(int(totbins)), _p(box), _p(h))
     return h
+
+
+# ---- water orientation -----------------------------------------------------
+def watorient(opos, hpos, refvec, boxl):
+    """waterlib.watorient -> (angdip[n], angplane[n]) in degrees"""
+    o = _d(opos); h = _d(hpos); box = _box(boxl); ref = np.ascontiguousarray(np.asarray(refvec, dtype=np.float64).reshape(-1)[:3])
+    if len(h) != 2 * len(o):
+        raise ValueError("Number of hydrogens must be two times number of oxygens.")
+    ad = np.empty(len(o)); ap = np.empty(len(o))
+    lib().wolo_wat_orient(_p(o), _p(h), C.c_int(len(o)), _p(ref), _p(box), _p(ad), _p(ap))
+    return ad, ap
+
+
+def watohvec(opos, hpos, boxl):
+    """waterlib.watohvec -> normdip[n,3] (Fortran order, as f2py returns it)"""
+    o = _d(opos); h = _d(hpos); box = _box(boxl)
+    if len(h) != 2 * len(o):
+        raise ValueError("Number of hydrogens must be two times number of oxygens.")
+    out = np.empty((len(o), 3))
+    lib().wolo_wat_oh_vec(_p(o), _p(h), C.c_int(len(o)), _p(box), _p(out))
+    return np.asfortranarray(out)

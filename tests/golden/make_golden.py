@@ -198,6 +198,18 @@ def main():
                         rdf_same_nonperiodic_z=wl.radialdistsame(posR, 0.1, 150, 1.0, boxR * np.array([1, 1, -1.0])))
     print("rdf700             first-shell peak g = %.3f (bulkdens 1 -> local density)" % wl.radialdistsame(posR, 0.1, 150, 1.0, boxR)[:40].max())
 
+    # (13) SURVEY 8f row f-2: water orientation (waterlib.f90:954-1044); hydrogens wrapped on their own so the
+    #      O-H vectors need the minimum-image step
+    xyzO, boxesO = synth.water_frames(500, 1, seed=41, len_wat=3)
+    fO, boxO = xyzO[0], boxesO[0]
+    Oo = fO[0::3].copy(); Ho = np.empty((1000, 3)); Ho[0::2] = fO[1::3]; Ho[1::2] = fO[2::3]
+    Ho = Ho - boxO * np.floor(Ho / boxO)
+    refO = np.array([0.3, -0.2, 1.0])
+    adO, apO = wl.watorient(Oo, Ho, refO, boxO)
+    np.savez_compressed(os.path.join(OUT, "orient500.npz"), opos=Oo, hpos=Ho, box=boxO, refvec=refO, angdip=adO,
+                        angplane=apO, normdip=wl.watohvec(Oo, Ho, boxO), angdip_z=wp.waterOrientation(Oo, Ho, boxO)[0])
+    print("orient500          <dipole angle> = %.2f deg" % adO.mean())
+
 
 if __name__ == "__main__":
     main()

@@ -464,3 +464,34 @@ def test_rdf_driver(tmp_path, monkeypatch):
     expect = (wl.radialdistsame(xyz[0], 0.1, 150, 1.0, boxes[0]) + wl.radialdistsame(xyz[1], 0.1, 150, 1.0, boxes[1])) / 2.0
     assert np.array_equal(rd[0], expect)
     assert np.loadtxt("rdf.txt").shape == (150, 7) and np.loadtxt("coord.txt").shape == (148, 7)
+
+
+# ---- water orientation ------------------------------------------------------------
+def test_orientation_golden_and_oracle(wp, oracle):
+    from waterorderlib_amd import synth, waterlib as wl
+    g = golden("orient500")
+    ad, ap = wl.watorient(g["opos"], g["hpos"], g["refvec"], g["box"])
+    np.testing.assert_allclose(ad, g["angdip"], rtol=0, atol=ANG_TOL)      # device acos vs glibc acos
+    np.testing.assert_allclose(ap, g["angplane"], rtol=0, atol=ANG_TOL)
+    nd = wl.watohvec(g["opos"], g["hpos"], g["box"])
+    assert nd.flags.f_contiguous and np.array_equal(nd, g["normdip"])       # no transcendental: bit-exact
+    np.testing.assert_allclose(wp.waterOrientation(g["opos"], g["hpos"], g["box"])[0], g["angdip_z"], rtol=0, atol=ANG_TOL)
+    # larger frame, molecules crossing the box faces, a non-periodic axis
+    xyz, boxes = synth.water_frames(20000, 1, seed=43, len_wat=3)
+    f, box = xyz[0], boxes[0] * np.array([1.0, 1.0, -1.0])
+    O = f[0::3]; H = np.empty((40000, 3)); H[0::2] = f[1::3]; H[1::2] = f[2::3]
+    H[:, :2] -= box[:2] * np.floor(H[:, :2] / box[:2])
+    ad, ap = wl.watorient(O, H, [1.0, 2.0, -0.5], box)
+    o_ad, o_ap = oracle.watorient(O, H, [1.0, 2.0, -0.5], box)
+    np.testing.assert_allclose(ad, o_ad, rtol=0, atol=ANG_TOL); np.testing.assert_allclose(ap, o_ap, rtol=0, atol=ANG_TOL)
+    assert np.array_equal(wl.watohvec(O, H, box), oracle.watohvec(O, H, box))
+    # a water lying in the xy plane with its dipole along +x
+    o1 = np.array([[5.0, 5.0, 5.0]]); h1 = np.array([[5.6, 5.8, 5.0], [5.6, 4.2, 5.0]])
+    ad, ap = wl.watorient(o1, h1, [1.0, 0.0, 0.0], boxes[0])
+    assert abs(ad[0]) < 1e-6 and abs(ap[0] - 90.0) < 1e-9
+    with pytest.raises(ValueError):
+        wl.watorient(O, H[:-1], [0.0, 0.0, 1.0], box)
+    with pytest.raises(RuntimeError):
+        wl.watorient(O, H, [0.0, 0.0, 0.0], box)
+    plane2d, dip2d = wp.waterOrientationBinZ(O, H, box)
+    assert plane2d.shape == dip2d.shape and plane2d.sum() <= len(O) and dip2d.sum() > 0.99 * len(O) - plane2d.shape[1]

@@ -121,3 +121,12 @@ def test_radial_distribution_functions(oracle):
     # every pair lands in exactly one bin when the range covers the box diagonal
     h = oracle.pairdistancehistogram(pos, pos, 0.5, 100, box)
     assert h.sum() == len(pos) * (len(pos) - 1)
+
+
+def test_water_orientation(oracle):
+    """SURVEY 8f row f-2 (waterlib.f90:954-1044): bit for bit against the reference's outputs"""
+    g = golden("orient500")
+    ad, ap = oracle.watorient(g["opos"], g["hpos"], g["refvec"], g["box"])
+    assert np.array_equal(ad, g["angdip"]) and np.array_equal(ap, g["angplane"])
+    assert np.array_equal(oracle.watohvec(g["opos"], g["hpos"], g["box"]), g["normdip"])
+    assert np.array_equal(oracle.watorient(g["opos"], g["hpos"], [0.0, 0.0, 1.0], g["box"])[0], g["angdip_z"])

@@ -21,7 +21,8 @@ SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy",
            "wol_near_neighbors", "wol_all_near_neighbors", "wol_tetra_cos_ang", "wol_lsi_dists",
            "wol_q_frame", "wol_cos_angs", "wol_lsi_frame", "wol_q_traj", "wol_q_traj_f32",
            "wol_willard_density_field", "wol_willard_density_points",
-           "wol_radial_dist_same", "wol_radial_dist", "wol_pair_distance_histogram"]
+           "wol_radial_dist_same", "wol_radial_dist", "wol_pair_distance_histogram",
+           "wol_wat_orient", "wol_wat_oh_vec"]
 
 _lib = None
 
@@ -82,6 +83,8 @@ def load():
     L.wol_radial_dist_same.argtypes = [_vp, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp]
     L.wol_radial_dist.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, C.c_double, _vp, _vp]
     L.wol_pair_distance_histogram.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]
+    L.wol_wat_orient.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
+    L.wol_wat_oh_vec.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp]
     traj = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, _vp,
             C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]
     L.wol_q_traj.argtypes = traj

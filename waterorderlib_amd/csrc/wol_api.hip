@@ -1186,6 +1186,47 @@ int wol_willard_density_points(wol_ctx* c, const double* pos, int n, const doubl
     return willard_impl(c, pos, n, pts, npts, nullptr, 0, nullptr, 0, nullptr, 0, box, smoothlen, densvals, densnorms);
 }
 
+// ---- water orientation ---------------------------------------------------------
+static int orient_impl(wol_ctx* c, const double* opos, const double* hpos, int n, const double* refvec, const double* box,
+                       double* out0, double* out1) {
+    WOL_TRY(check_ctx(c));
+    if (!opos || !hpos || !box || !out0 || n < 0) return fail(WOL_ERR_INVALID, "orientation: bad argument");
+    if (n == 0) return WOL_OK;
+    const size_t nb = sizeof(double) * 3 * (size_t)n;
+    WOL_TRY(c->in_stage.ensure(3 * nb));
+    WOL_TRY(c->out_stage.ensure(nb));
+    double* d_o = c->in_stage.as<double>();
+    double* d_h = d_o + 3 * (size_t)n;
+    double* d_out = c->out_stage.as<double>();
+    HIP_TRY(hipMemcpyAsync(d_o, opos, nb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_h, hpos, 2 * nb, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid((n + 255) / 256);
+    if (refvec) {
+        hipLaunchKernelGGL(k_wat_orient, grid, dim3(256), 0, c->stream, d_o, d_h, n, refvec[0], refvec[1], refvec[2],
+                           make_box(box), d_out, d_out + n);
+        HIP_TRY(hipMemcpyAsync(out0, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out1, d_out + n, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        hipLaunchKernelGGL(k_wat_oh_vec, grid, dim3(256), 0, c->stream, d_o, d_h, n, make_box(box), d_out);
+        HIP_TRY(hipMemcpyAsync(out0, d_out, nb, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+int wol_wat_orient(wol_ctx* c, const double* opos, const double* hpos, int n, const double* refvec, const double* box,
+                   double* angdip, double* angplane) {
+    if (!refvec || !angplane) return fail(WOL_ERR_INVALID, "watorient: bad argument");
+    if (!((refvec[0] * refvec[0] + refvec[1] * refvec[1]) + refvec[2] * refvec[2] > 0.0))
+        return fail(WOL_ERR_INVALID, "watorient: reference vector must not be zero");
+    return orient_impl(c, opos, hpos, n, refvec, box, angdip, angplane);
+}
+
+int wol_wat_oh_vec(wol_ctx* c, const double* opos, const double* hpos, int n, const double* box, double* normdip) {
+    return orient_impl(c, opos, hpos, n, nullptr, box, normdip, nullptr);
+}
+
 // ---- radial distribution functions --------------------------------------------
 // counts of pair distances per bin: candidates = pos2 (cell-sorted), queries = pos1 (null: pos2 itself, pairs once)
 static int pair_counts_impl(wol_ctx* c, const double* pos1, int n1, const double* pos2, int n2, double binwidth,

@@ -730,3 +730,57 @@ __global__ void k_lsi_dists(const double* __restrict__ neigh, int n, double r0, 
     const double dz = wol_minimg1(neigh[3 * (int64_t)i + 2] - r2, box.L[2], box.ib[2]);
     dist[i] = sqrt(wol_sumsq(dx, dy, dz));
 }
+
+// =============================================================================================
+// water orientation (waterlib.f90:954-1044: AngBetween, watOrient, watOHvec).
+// One lane per water: 72 B in (O, H1, H2), 16 B (two angles) or 24 B (unit dipole) out -- HBM-bound streaming.
+// =============================================================================================
+__device__ __forceinline__ double wol_ang_between(const double a[3], const double b[3]) {
+    const double pi = WOL_PI;
+    const double DegPerRad = 180.0 / pi;
+    double phi = fmin(1.0, fmax(-1.0, (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]));
+    phi = acos(phi);
+    double r = fmod(phi + pi, pi * 2.0) - pi;
+    if (r < -pi) r = r + pi * 2.0;
+    return r * DegPerRad;
+}
+
+__device__ __forceinline__ void wol_oh_vectors(const double* __restrict__ opos, const double* __restrict__ hpos, int i,
+                                               const Box3& b, double v1[3], double v2[3], double dip[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double o = opos[3 * (int64_t)i + k];
+        v1[k] = wol_minimg1(hpos[6 * (int64_t)i + k] - o, b.L[k], b.ib[k]);
+        v2[k] = wol_minimg1(hpos[6 * (int64_t)i + 3 + k] - o, b.L[k], b.ib[k]);
+        dip[k] = wol_minimg1(v1[k] + v2[k], b.L[k], b.ib[k]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_wat_orient(const double* __restrict__ opos, const double* __restrict__ hpos, int n, double r0, double r1, double r2,
+             Box3 b, double* __restrict__ angdip, double* __restrict__ angplane) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double rn = sqrt(wol_sumsq(r0, r1, r2));
+    const double ref[3] = {r0 / rn, r1 / rn, r2 / rn};
+    double v1[3], v2[3], dip[3], u[3];
+    wol_oh_vectors(opos, hpos, i, b, v1, v2, dip);
+    const double nd = sqrt(wol_sumsq(dip[0], dip[1], dip[2]));
+    u[0] = dip[0] / nd; u[1] = dip[1] / nd; u[2] = dip[2] / nd;
+    angdip[i] = wol_ang_between(u, ref);
+    const double pl[3] = {v1[1] * v2[2] - v1[2] * v2[1], v1[2] * v2[0] - v1[0] * v2[2], v1[0] * v2[1] - v1[1] * v2[0]};
+    const double np_ = sqrt(wol_sumsq(pl[0], pl[1], pl[2]));
+    u[0] = pl[0] / np_; u[1] = pl[1] / np_; u[2] = pl[2] / np_;
+    angplane[i] = wol_ang_between(u, ref);
+}
+
+__global__ void __launch_bounds__(256)
+k_wat_oh_vec(const double* __restrict__ opos, const double* __restrict__ hpos, int n, Box3 b, double* __restrict__ normdip) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double v1[3], v2[3], dip[3];
+    wol_oh_vectors(opos, hpos, i, b, v1, v2, dip);
+    const double nd = sqrt(wol_sumsq(dip[0], dip[1], dip[2]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) normdip[3 * (int64_t)i + k] = dip[k] / nd;
+}

@@ -11,6 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from . import waterlib as wl
 
 watdens = 0.033456  # molecules or oxygens per Angstrom ^ 3 near 300 K (water_properties.py:55)
 
@@ -105,3 +106,27 @@ def tetrahedralMetrics(angVals, nBins=500, binRange=[0.0, 180.0]):
     angDens = angDens[np.where(angDens != 0)[0]]
     entropy = -np.sum(angDens * np.log(angDens))
     return angDist, bins, fracTet, avgCos, varCos, entropy
+
+
+def waterOrientation(Opos, Hpos, boxDim, refVec=[0.0, 0.0, 1.0]):
+    """water_properties.py:621-638: (dipAngs, planeAngs) of wl.watorient"""
+    return wl.watorient(Opos, Hpos, refVec, boxDim)
+
+
+def waterOrientationBinZ(Opos, Hpos, boxDim, refVec=[0.0, 0.0, 1.0], refBins=None, angBins=None):
+    """water_properties.py:578-618: 2-D histograms (angle x position along refVec) of the plane-normal and dipole
+    angles.  The reference's own body no longer runs -- np.histogram2d lost `normed`, and it pairs the per-water
+    plane angles with a per-hydrogen position list -- so this follows its evident intent: both histograms are taken
+    against the oxygen position along refVec.  Returns (plane2Dhist, dip2Dhist)."""
+    refVec = np.asarray(refVec, dtype=np.float64)
+    refVec = refVec / np.linalg.norm(refVec)
+    Opos = np.asarray(Opos, dtype=np.float64)
+    zOpos = np.dot(Opos, refVec)
+    angDip, angPlane = wl.watorient(Opos, Hpos, refVec, boxDim)
+    if refBins is None:
+        refBins = np.arange(np.min(zOpos), np.max(zOpos), 0.2)
+    if angBins is None:
+        angBins = np.arange(0.0, 180.001, 180.0 / 500.0)
+    plane2Dhist, _, _ = np.histogram2d(angPlane, zOpos, bins=[angBins, refBins])
+    dip2Dhist, _, _ = np.histogram2d(angDip, zOpos, bins=[angBins, refBins])
+    return plane2Dhist, dip2Dhist

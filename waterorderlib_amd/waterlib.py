@@ -142,3 +142,28 @@ def pairdistancehistogram(pos1, pos2, binwidth, totbins, boxl, npos1=None, npos2
                                                        len(p2), float(binwidth), int(totbins), _lib.ptr(box),
                                                        _lib.ptr(hist)))
     return hist
+
+
+def _oh(opos, hpos):
+    o = _pos(opos, "opos"); h = _pos(hpos, "hpos")
+    if len(h) != 2 * len(o):   # the Fortran prints this and stops the interpreter (waterlib.f90:989-992)
+        raise ValueError("Number of hydrogens must be two times number of oxygens.")
+    return o, h
+
+
+def watorient(opos, hpos, refvec, boxl, nopos=None, nhpos=None):
+    """angdip,angplane = watorient(opos,hpos,refvec,boxl,[nopos,nhpos]) -- waterlib.f90:973-1011"""
+    o, h = _oh(opos, hpos); ref = _vec3(refvec, "refvec"); box = _lib.box3(boxl)
+    ad = np.empty(len(o), dtype=np.float64); ap = np.empty(len(o), dtype=np.float64)
+    _lib.check(_lib.load().wol_wat_orient(_lib.default_context().handle, _lib.ptr(o), _lib.ptr(h), len(o), _lib.ptr(ref),
+                                          _lib.ptr(box), _lib.ptr(ad), _lib.ptr(ap)))
+    return ad, ap
+
+
+def watohvec(opos, hpos, boxl, nopos=None, nhpos=None):
+    """normdip = watohvec(opos,hpos,boxl,[nopos,nhpos]) -- waterlib.f90:1019-1044, (n,3) Fortran order"""
+    o, h = _oh(opos, hpos); box = _lib.box3(boxl)
+    out = np.empty((len(o), 3), dtype=np.float64)
+    _lib.check(_lib.load().wol_wat_oh_vec(_lib.default_context().handle, _lib.ptr(o), _lib.ptr(h), len(o), _lib.ptr(box),
+                                          _lib.ptr(out)))
+    return np.asfortranarray(out)
