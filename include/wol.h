@@ -151,6 +151,20 @@ int wol_radial_dist(wol_ctx* ctx, const double* pos1, int n1, const double* pos2
 int wol_pair_distance_histogram(wol_ctx* ctx, const double* pos1, int n1, const double* pos2, int n2,
                                 double binwidth, int totbins, const double* box, double* hist);
 
+/* ---- "next" row f-4: hydrogen bonds ------------------------------------------------ */
+/* waterlib.f90:1156-1210 generalHbonds (called four times per frame by orderParam_lib.getBoundWrap, :519-545):
+ * bond (nacc, ndon) Fortran-order int32, 1 where acceptor i and donor j (heavy atom don[j], hydrogen
+ * donh[j]) are hydrogen bonded: 1.0E-2 < |D-A|^2 <= distCut^2 and angle(A-H, D-H) >= angCut degrees. */
+int wol_general_hbonds(wol_ctx* ctx, const double* acc, int nacc, const double* don, const double* donh,
+                       int ndon, const double* box, double distcut, double angcut, int32_t* bond);
+/* The same bonds as a list (acceptor, donor), ascending -- np.where(bondBool) -- through the cell list, for
+ * frames whose mask would not fit.  *count = bonds found; if it exceeds capacity only the first
+ * `capacity` (in no particular selection) are returned: call again with a larger buffer. */
+int wol_general_hbonds_list(wol_ctx* ctx, const double* acc, int nacc, const double* don,
+                            const double* donh, int ndon, const double* box, double distcut,
+                            double angcut, int64_t capacity, int32_t* acc_idx, int32_t* don_idx,
+                            int64_t* count);
+
 /* ---- level 3: the tetOrderCalc frame loop (orderParam_lib.py:1458-1495) ------------------- */
 /* T frames of n waters each; water w of frame t is at frames + t*frame_stride + w*atom_stride
  * (strides in doubles).  boxes is host [T][3].  Per frame: q for every water (sub == pos branch),

@@ -736,3 +736,41 @@ void wolo_wat_oh_vec(const double* opos, const double* hpos, int n, const double
         for (int k = 0; k < 3; ++k) normdip[3 * (size_t)i + k] = dip[k] / nd;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * hydrogen bonds.  waterlib.f90:1156-1210 generalHbonds: acceptor i and donor j are
+ * bonded when 1.0E-2 < |D - A|^2 <= distCut^2 (minimum image; the lower bound is a single-precision literal) and
+ * the angle at the donor hydrogen between (A - H) and (D - H), both imaged and normalised, is >= angCut degrees.
+ * bond is (nacc, ndon) in Fortran order, int32 as f2py returns logicals.
+ * ------------------------------------------------------------------------------------------ */
+int wolo_hbond_pair(const double* a, const double* d, const double* h, const double box[3], const double ib[3],
+                    double distcutsq, double angcut) {
+    double v[3], av[3], dv[3];
+    for (int k = 0; k < 3; ++k) {
+        const double t = d[k] - a[k];
+        v[k] = t - box[k] * round(t * ib[k]);
+    }
+    const double dsq = sumsq3(v);
+    if (dsq > distcutsq || dsq <= (double)1.0E-2f) return 0;
+    for (int k = 0; k < 3; ++k) {
+        double t = a[k] - h[k];
+        av[k] = t - box[k] * round(t * ib[k]);
+        t = d[k] - h[k];
+        dv[k] = t - box[k] * round(t * ib[k]);
+    }
+    const double na = sqrt(sumsq3(av)), nd = sqrt(sumsq3(dv));
+    for (int k = 0; k < 3; ++k) { av[k] = av[k] / na; dv[k] = dv[k] / nd; }
+    return ang_between(av, dv) < angcut ? 0 : 1;
+}
+
+void wolo_general_hbonds(const double* acc, int nacc, const double* don, const double* donh, int ndon,
+                         const double box[3], double distcut, double angcut, int32_t* bond) {
+    double ib[3];
+    ibox_of(box, ib);
+    const double dcs = distcut * distcut;
+    #pragma omp parallel for schedule(static)
+    for (int j = 0; j < ndon; ++j)
+        for (int i = 0; i < nacc; ++i)
+            bond[(size_t)j * nacc + i] = wolo_hbond_pair(acc + 3 * (size_t)i, don + 3 * (size_t)j, donh + 3 * (size_t)j,
+                                                         box, ib, dcs, angcut);
+}

@@ -251,3 +251,15 @@ def watohvec(opos, hpos, boxl):
     out = np.empty((len(o), 3))
     lib().wolo_wat_oh_vec(_p(o), _p(h), C.c_int(len(o)), _p(box), _p(out))
     return np.asfortranarray(out)
+
+
+# ---- hydrogen bonds ---------------------------------------------------------
+def generalhbonds(acceptorpos, donorpos, donorhpos, boxl, distcut, angcut):
+    """waterlib.generalhbonds -> bondbool (nacc, ndon) int32, Fortran order"""
+    a = _d(acceptorpos); d = _d(donorpos); h = _d(donorhpos); box = _box(boxl)
+    if len(d) != len(h):
+        raise ValueError("Number of donor hydrogens and heavy-atoms do not match.")
+    out = np.zeros((len(a), len(d)), dtype=np.int32, order="F")
+    lib().wolo_general_hbonds(_p(a), C.c_int(len(a)), _p(d), _p(h), C.c_int(len(d)), _p(box), C.c_double(distcut),
+                              C.c_double(angcut), out.ctypes.data_as(C.c_void_p))
+    return out

@@ -210,6 +210,16 @@ def main():
                         angplane=apO, normdip=wl.watohvec(Oo, Ho, boxO), angdip_z=wp.waterOrientation(Oo, Ho, boxO)[0])
     print("orient500          <dipole angle> = %.2f deg" % adO.mean())
 
+    # (14) SURVEY 8f row f-4: hydrogen bonds (waterlib.f90:1156-1210), every water oxygen as acceptor, every O-H as donor
+    xyzB, boxesB = synth.water_frames(600, 1, seed=51, len_wat=3)
+    fB, boxB = xyzB[0], boxesB[0]
+    Ob = fB[0::3].copy(); donB = np.repeat(Ob, 2, axis=0); Hb = np.empty((1200, 3)); Hb[0::2] = fB[1::3]; Hb[1::2] = fB[2::3]
+    b1 = wl.generalhbonds(Ob, donB, Hb, boxB, 3.0, 150.0); b2 = wl.generalhbonds(Ob, donB, Hb, boxB, 3.5, 120.0)
+    np.savez_compressed(os.path.join(OUT, "hbonds600.npz"), acc=Ob, don=donB, donh=Hb, box=boxB,
+                        pairs_3p0_150=np.stack(np.where(b1 == 1), axis=1).astype(np.int32),
+                        pairs_3p5_120=np.stack(np.where(b2 == 1), axis=1).astype(np.int32))
+    print("hbonds600          bonds at (3.0 A, 150 deg): %d, at (3.5 A, 120 deg): %d" % (b1.sum(), b2.sum()))
+
 
 if __name__ == "__main__":
     main()

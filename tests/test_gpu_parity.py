@@ -495,3 +495,61 @@ def test_orientation_golden_and_oracle(wp, oracle):
         wl.watorient(O, H, [0.0, 0.0, 0.0], box)
     plane2d, dip2d = wp.waterOrientationBinZ(O, H, box)
     assert plane2d.shape == dip2d.shape and plane2d.sum() <= len(O) and dip2d.sum() > 0.99 * len(O) - plane2d.shape[1]
+
+
+# ---- hydrogen bonds ------------------------------------------------------------------
+def _water_hb_arrays(f):
+    O = f[0::3].copy(); H = np.empty((2 * len(O), 3)); H[0::2] = f[1::3]; H[1::2] = f[2::3]
+    return O, np.repeat(O, 2, axis=0), H
+
+
+def test_hbonds_golden_and_oracle(oracle):
+    """bit-exact decisions (the angle test uses the device acos: a flip needs an angle within ~1e-12 deg of the cut)"""
+    from waterorderlib_amd import synth, waterlib as wl
+    g = golden("hbonds600")
+    for key, (dc, ac) in (("pairs_3p0_150", (3.0, 150.0)), ("pairs_3p5_120", (3.5, 120.0))):
+        b = wl.generalhbonds(g["acc"], g["don"], g["donh"], g["box"], dc, ac)
+        assert b.dtype == np.int32 and b.flags.f_contiguous
+        assert np.array_equal(np.stack(np.where(b == 1), axis=1), g[key])
+        ai, di = wl.generalhbonds_list(g["acc"], g["don"], g["donh"], g["box"], dc, ac)
+        assert np.array_equal(np.stack([ai, di], axis=1), g[key])
+    # larger frame through the cell list vs the oracle's dense mask; acceptors that are not the donors' atoms;
+    # a non-periodic axis (all-pairs walk)
+    oracle.set_threads(8)
+    xyz, boxes = synth.water_frames(5000, 1, seed=53, len_wat=3)
+    O, don, H = _water_hb_arrays(xyz[0])
+    for box in (boxes[0], boxes[0] * np.array([1.0, -1.0, 1.0])):
+        ref = oracle.generalhbonds(O[:1500], don, H, box, 3.5, 130.0)
+        ai, di = wl.generalhbonds_list(O[:1500], don, H, box, 3.5, 130.0)
+        assert np.array_equal(np.stack([ai, di], axis=1), np.stack(np.where(ref == 1), axis=1))
+        assert np.array_equal(wl.generalhbonds(O[:1500], don, H, box, 3.5, 130.0), ref)
+    ai, di = wl.generalhbonds_list(O, don, H, boxes[0], 3.5, 120.0)
+    assert len(ai) > len(O) // 2 and not np.any(ai == di // 2)          # a water never bonds to itself
+    assert wl.generalhbonds(np.zeros((0, 3)), don, H, boxes[0], 3.0, 150.0).shape == (0, len(don))
+    with pytest.raises(ValueError):
+        wl.generalhbonds(O, don[:-1], H, boxes[0], 3.0, 150.0)
+
+
+def test_bound_wrap_driver(oracle):
+    """getBoundWrap (orderParam_lib.py:419-572) on arrays: shell / bound / wrap sets against the same logic run on the
+    oracle's masks"""
+    from waterorderlib_amd import synth, orderParam_lib as opl
+    xyz, boxes = synth.water_frames(1500, 1, seed=57, len_wat=3)
+    f, box = xyz[0], boxes[0]
+    rng = np.random.default_rng(58)
+    # a toy solute: 6 hydroxyl-like sites O-H placed in the box
+    so = rng.random((6, 3)) * box
+    sh = so + 0.96 * np.array([[1.0, 0.0, 0.0]])
+    pos = np.concatenate([f, so, sh])
+    nw = len(f)
+    watInds = np.arange(0, nw, 3)
+    solInds = np.arange(nw, nw + 6)
+    solH = np.arange(nw + 6, nw + 12)
+    bound, wrap, shell, non = opl.getBoundWrap(pos, box, watInds, 3, solInds, solInds, solInds, solH, cutoff=4.0, hbDist=3.5, hbAng=120.0)
+    nb = oracle.nearneighbors(pos[solInds], pos[watInds], box, 0.0, 4.0)
+    assert np.array_equal(shell, watInds[np.unique(np.where(nb == 1)[1])])
+    assert len(bound) + len(wrap) == len(shell) and len(shell) + len(non) == len(watInds) and len(shell) > 0
+    acc_w = oracle.generalhbonds(pos[shell], pos[solInds], pos[solH], box, 3.5, 120.0)
+    don_w = oracle.generalhbonds(pos[solInds], pos[np.repeat(shell, 2)], pos[(np.repeat(shell, 2).reshape(-1, 2) + [1, 2]).reshape(-1)], box, 3.5, 120.0)
+    expect = np.union1d(np.where(acc_w == 1)[0], np.where(don_w == 1)[1] // 2)
+    assert np.array_equal(bound, shell[expect])

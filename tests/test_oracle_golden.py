@@ -130,3 +130,12 @@ def test_water_orientation(oracle):
     assert np.array_equal(ad, g["angdip"]) and np.array_equal(ap, g["angplane"])
     assert np.array_equal(oracle.watohvec(g["opos"], g["hpos"], g["box"]), g["normdip"])
     assert np.array_equal(oracle.watorient(g["opos"], g["hpos"], [0.0, 0.0, 1.0], g["box"])[0], g["angdip_z"])
+
+
+def test_general_hbonds(oracle):
+    """SURVEY 8f row f-4 (waterlib.f90:1156-1210): the bond set equals the reference's"""
+    g = golden("hbonds600")
+    for key, (dc, ac) in (("pairs_3p0_150", (3.0, 150.0)), ("pairs_3p5_120", (3.5, 120.0))):
+        b = oracle.generalhbonds(g["acc"], g["don"], g["donh"], g["box"], dc, ac)
+        assert b.dtype == np.int32 and b.flags.f_contiguous and b.shape == (600, 1200)
+        assert np.array_equal(np.stack(np.where(b == 1), axis=1), g[key])

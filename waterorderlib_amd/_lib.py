@@ -22,7 +22,7 @@ SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy",
            "wol_q_frame", "wol_cos_angs", "wol_lsi_frame", "wol_q_traj", "wol_q_traj_f32",
            "wol_willard_density_field", "wol_willard_density_points",
            "wol_radial_dist_same", "wol_radial_dist", "wol_pair_distance_histogram",
-           "wol_wat_orient", "wol_wat_oh_vec"]
+           "wol_wat_orient", "wol_wat_oh_vec", "wol_general_hbonds", "wol_general_hbonds_list"]
 
 _lib = None
 
@@ -85,6 +85,9 @@ def load():
     L.wol_pair_distance_histogram.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_double, C.c_int, _vp, _vp]
     L.wol_wat_orient.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]
     L.wol_wat_oh_vec.argtypes = [_vp, _vp, _vp, C.c_int, _vp, _vp]
+    L.wol_general_hbonds.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, _vp]
+    L.wol_general_hbonds_list.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_int64,
+                                          _vp, _vp, _vp]
     traj = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, _vp,
             C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]
     L.wol_q_traj.argtypes = traj

@@ -5,6 +5,7 @@
 #include "wol_search_rows.hip"
 #include "wol_shell.hip"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1293,6 +1294,64 @@ int wol_pair_distance_histogram(wol_ctx* c, const double* pos1, int n1, const do
     std::vector<long long> counts;
     WOL_TRY(pair_counts_impl(c, pos1, n1, pos2, n2, binwidth, totbins, box, &counts));
     for (int k = 0; k < totbins; ++k) hist[k] = (double)counts[(size_t)k];
+    return WOL_OK;
+}
+
+// ---- hydrogen bonds --------------------------------------------------------------
+int wol_general_hbonds(wol_ctx* c, const double* acc, int nacc, const double* don, const double* donh, int ndon,
+                       const double* box, double distcut, double angcut, int32_t* bond) {
+    WOL_TRY(check_ctx(c));
+    if (!acc || !don || !donh || !box || !bond || nacc < 0 || ndon < 0) return fail(WOL_ERR_INVALID, "generalhbonds: bad argument");
+    const int64_t total = (int64_t)nacc * ndon;
+    if (total == 0) return WOL_OK;
+    if (total > (int64_t)1 << 33) return fail(WOL_ERR_INVALID, "generalhbonds: a %d x %d mask is too large; use wol_general_hbonds_list", nacc, ndon);
+    const size_t ab = sizeof(double) * 3 * (size_t)nacc, db = sizeof(double) * 3 * (size_t)ndon;
+    WOL_TRY(c->in_stage.ensure(ab + 2 * db));
+    WOL_TRY(c->out_stage.ensure(sizeof(int32_t) * (size_t)total));
+    double* d_a = c->in_stage.as<double>();
+    double* d_d = d_a + 3 * (size_t)nacc;
+    double* d_h = d_d + 3 * (size_t)ndon;
+    HIP_TRY(hipMemcpyAsync(d_a, acc, ab, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, don, db, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_h, donh, db, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_hbonds_dense, dim3((unsigned)((total + WOL_BLOCK - 1) / WOL_BLOCK)), dim3(WOL_BLOCK), 0, c->stream,
+                       d_a, nacc, d_d, d_h, ndon, make_box(box), distcut * distcut, angcut, c->out_stage.as<int32_t>());
+    HIP_TRY(hipMemcpyAsync(bond, c->out_stage.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+int wol_general_hbonds_list(wol_ctx* c, const double* acc, int nacc, const double* don, const double* donh, int ndon,
+                            const double* box, double distcut, double angcut, int64_t capacity, int32_t* acc_idx,
+                            int32_t* don_idx, int64_t* count) {
+    WOL_TRY(check_ctx(c));
+    if (!acc || !don || !donh || !box || !count || nacc < 0 || ndon < 0 || capacity < 0 || (capacity > 0 && (!acc_idx || !don_idx)))
+        return fail(WOL_ERR_INVALID, "generalhbonds list: bad argument");
+    if (!(distcut > 0.0)) return fail(WOL_ERR_INVALID, "generalhbonds list: distCut must be > 0");
+    *count = 0;
+    if (nacc == 0 || ndon == 0) return WOL_OK;
+    ShellArgs sa;
+    WOL_TRY(shell_setup(c, don, ndon, acc, nacc, box, distcut, &sa));
+    WOL_TRY(c->out_stage.ensure(sizeof(double) * 3 * (size_t)ndon));
+    WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)std::max<int64_t>(capacity, 1)));
+    WOL_TRY(c->small.ensure(sizeof(unsigned long long)));
+    HIP_TRY(hipMemcpyAsync(c->out_stage.p, donh, sizeof(double) * 3 * (size_t)ndon, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->small.p, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_hbonds_list, dim3((nacc + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream, sa,
+                       c->out_stage.as<double>(), distcut * distcut, angcut, c->slow_list.as<unsigned long long>(),
+                       (unsigned long long)capacity, c->small.as<unsigned long long>());
+    unsigned long long found = 0;
+    HIP_TRY(hipMemcpyAsync(&found, c->small.p, sizeof found, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    *count = (int64_t)found;   // may exceed capacity: call again with a larger buffer
+    const size_t got = (size_t)std::min<unsigned long long>(found, (unsigned long long)capacity);
+    if (got == 0) return WOL_OK;
+    std::vector<unsigned long long> pairs(got);
+    HIP_TRY(hipMemcpy(pairs.data(), c->slow_list.p, sizeof(unsigned long long) * got, hipMemcpyDeviceToHost));
+    std::sort(pairs.begin(), pairs.end());   // (acceptor, donor) ascending: the order of np.where(bondBool)
+    for (size_t k = 0; k < got; ++k) { acc_idx[k] = (int32_t)(pairs[k] >> 32); don_idx[k] = (int32_t)(pairs[k] & 0xFFFFFFFFu); }
     return WOL_OK;
 }
 

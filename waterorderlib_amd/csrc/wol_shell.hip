@@ -327,3 +327,60 @@ k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long l
     __syncthreads();
     wol_hist_flush(lds_hist, totbins, hist);
 }
+
+// ---------------------------------------------------------------------------------------------
+// hydrogen bonds (waterlib.f90:1156-1210 generalHbonds; caller orderParam_lib.getBoundWrap
+// :419-572).  The pair test in the reference's arithmetic; two drivers: a dense (nacc, ndon) Fortran-order int32
+// mask for f2py compatibility (one thread per element, like the reference's O(nacc*ndon) loop) and a sparse
+// list through the cell list on the donors (reach distCut), for frames where the mask would not fit.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wol_hbond_pair(const double a[3], const double d[3], const double* __restrict__ h,
+                                               const Box3& b, double distcutsq, double angcut) {
+    double av[3], dv[3];
+    const double v0 = wol_minimg1(d[0] - a[0], b.L[0], b.ib[0]), v1 = wol_minimg1(d[1] - a[1], b.L[1], b.ib[1]);
+    const double v2 = wol_minimg1(d[2] - a[2], b.L[2], b.ib[2]);
+    const double dsq = wol_sumsq(v0, v1, v2);
+    if (dsq > distcutsq || dsq <= (double)1.0E-2f) return false;   // single-precision literal, as the Fortran
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        av[k] = wol_minimg1(a[k] - h[k], b.L[k], b.ib[k]);
+        dv[k] = wol_minimg1(d[k] - h[k], b.L[k], b.ib[k]);
+    }
+    const double na = sqrt(wol_sumsq(av[0], av[1], av[2])), nd = sqrt(wol_sumsq(dv[0], dv[1], dv[2]));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { av[k] = av[k] / na; dv[k] = dv[k] / nd; }
+    return !(wol_ang_between(av, dv) < angcut);
+}
+
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_hbonds_dense(const double* __restrict__ acc, int nacc, const double* __restrict__ don, const double* __restrict__ donh,
+               int ndon, Box3 b, double distcutsq, double angcut, int32_t* __restrict__ bond) {
+    const int64_t e = (int64_t)blockIdx.x * WOL_BLOCK + threadIdx.x;   // element of the (nacc, ndon) Fortran-order mask
+    if (e >= (int64_t)nacc * ndon) return;
+    const int j = (int)(e / nacc), i = (int)(e - (int64_t)j * nacc);
+    const double a[3] = {acc[3 * (int64_t)i], acc[3 * (int64_t)i + 1], acc[3 * (int64_t)i + 2]};
+    const double d[3] = {don[3 * (int64_t)j], don[3 * (int64_t)j + 1], don[3 * (int64_t)j + 2]};
+    bond[e] = wol_hbond_pair(a, d, donh + 3 * (int64_t)j, b, distcutsq, angcut) ? 1 : 0;
+}
+
+// sparse form: a.sorted = cell-sorted donors, a.sub = acceptors; pairs appended as (acceptor << 32 | donor)
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_hbonds_list(ShellArgs a, const double* __restrict__ donh, double distcutsq, double angcut,
+              unsigned long long* __restrict__ pairs, unsigned long long capacity, unsigned long long* __restrict__ count) {
+    const int q = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (q >= a.ns) return;
+    double c[3];
+    int row;
+    wol_shell_query(a, q, c, &row);
+    const Box3& b = a.grid->box;
+    wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
+        if (d2 > distcutsq || d2 <= (double)1.0E-2f) return;   // the test inside wol_hbond_pair again: cheap pre-filter
+        const double4 dn = a.sorted[slot];
+        const int j = (int)__double_as_longlong(dn.w);
+        const double d[3] = {dn.x, dn.y, dn.z};
+        if (wol_hbond_pair(c, d, donh + 3 * (int64_t)j, b, distcutsq, angcut)) {
+            const unsigned long long pos = atomicAdd(count, 1ull);
+            if (pos < capacity) pairs[pos] = ((unsigned long long)(unsigned)row << 32) | (unsigned)j;
+        }
+    });
+}

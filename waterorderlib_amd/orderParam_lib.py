@@ -264,3 +264,42 @@ def rdfCalc(topFile, trajFile=None, solResName='(!:WAT)', watResName='(:WAT)', b
                 [np.mean(tot_n1_SolOw), np.std(np.array(tot_n1_SolOw), ddof=1) / np.sqrt(nChunks - 1)],
                 [tParam, np.std(np.array(tot_tParam), ddof=1) / np.sqrt(nChunks - 1)])
     return n1_OwOw, tParam
+
+
+def getBoundWrap(pos, thisbox, watInds, lenWat, solInds, sol_acceptorOInds, sol_donorOInds, sol_donorHOInds,
+                 cutoff=4.0, hbDist=3.0, hbAng=150.0):
+    """orderParam_lib.py:419-572: bound / wrap / shell / non-shell water-oxygen indices of one frame.
+
+    The reference derives the hydrogen-bond partner lists from a parmed topology (getHBInds, :46-120); an
+    array-backed caller passes them: the solute's acceptor oxygens, and its donor oxygens listed once per bonded
+    hydrogen next to those hydrogens' indices.  Waters are O,H1,H2[,EP] blocks of `lenWat` atoms, as getWatInds
+    yields them, so a shell water with oxygen index o contributes acceptor o and donors (o, o+1), (o, o+2) -- what
+    getHBInds returns for it.  Shell = waters within `cutoff` of any solute heavy atom (wl.nearneighbors, :497);
+    bound = shell waters hydrogen-bonded to the solute in either direction (wl.generalhbonds, :519-560)."""
+    from . import waterlib as wl
+    pos = np.asarray(pos, dtype=np.float64)
+    thisbox = np.asarray(thisbox, dtype=np.float64).reshape(-1)[:3]
+    watInds = np.asarray(watInds, dtype=int)
+    watPos = pos[watInds]
+    solPos = pos[np.asarray(solInds, dtype=int)]
+    neighbors = wl.nearneighbors(solPos, watPos, thisbox, 0.0, cutoff)
+    mask = np.unique(np.where(neighbors == 1)[1])
+    shellInds = watInds[mask]
+    nonShellInds = np.delete(watInds, mask)
+    wat_acceptorOPos = pos[shellInds]
+    wat_donorOPos = pos[np.repeat(shellInds, 2)]
+    wat_donorHOPos = pos[(np.repeat(shellInds, 2).reshape(-1, 2) + np.array([1, 2])).reshape(-1)] if lenWat >= 3 else np.zeros((0, 3))
+    sol_acceptorOPos = pos[np.asarray(sol_acceptorOInds, dtype=int)]
+    sol_donorOPos = pos[np.asarray(sol_donorOInds, dtype=int)]
+    sol_donorHOPos = pos[np.asarray(sol_donorHOInds, dtype=int)]
+    # water accepts from the solute (:541-545), solute accepts from water (:548-556)
+    watSolHBs = wl.generalhbonds(wat_acceptorOPos, sol_donorOPos, sol_donorHOPos, thisbox, hbDist, hbAng)
+    boundMask_wat = np.unique(np.where(watSolHBs == 1)[0])
+    solWatHBs = wl.generalhbonds(sol_acceptorOPos, wat_donorOPos, wat_donorHOPos, thisbox, hbDist, hbAng)
+    dummy = np.zeros(len(wat_donorOPos))
+    dummy[np.unique(np.where(solWatHBs == 1)[1])] = 1
+    boundMask_sol = np.where(np.ceil(0.5 * (dummy[0::2] + dummy[1::2])))[0]
+    boundMask = np.sort(np.unique(np.concatenate([boundMask_wat, boundMask_sol]))).astype(int)
+    m = np.ones(len(shellInds), dtype=bool)
+    m[boundMask] = False
+    return shellInds[boundMask], shellInds[m], shellInds, nonShellInds

@@ -167,3 +167,34 @@ def watohvec(opos, hpos, boxl, nopos=None, nhpos=None):
     _lib.check(_lib.load().wol_wat_oh_vec(_lib.default_context().handle, _lib.ptr(o), _lib.ptr(h), len(o), _lib.ptr(box),
                                           _lib.ptr(out)))
     return np.asfortranarray(out)
+
+
+def _hb_args(acceptorpos, donorpos, donorhpos, boxl):
+    a = _pos(acceptorpos, "acceptorpos"); d = _pos(donorpos, "donorpos"); h = _pos(donorhpos, "donorhpos")
+    if len(d) != len(h):   # the Fortran prints this and stops the interpreter (waterlib.f90:1173-1176)
+        raise ValueError("Number of donor hydrogens and heavy-atoms do not match.")
+    return a, d, h, _lib.box3(boxl)
+
+
+def generalhbonds(acceptorpos, donorpos, donorhpos, boxl, distcut, angcut, nacc=None, ndon=None, ndonh=None):
+    """bondbool = generalhbonds(acceptorpos,donorpos,donorhpos,boxl,distcut,angcut,[nacc,ndon,ndonh]) --
+    waterlib.f90:1156-1210; (nacc, ndon) Fortran-ordered int32 like f2py's logical arrays"""
+    a, d, h, box = _hb_args(acceptorpos, donorpos, donorhpos, boxl)
+    out = np.zeros((len(a), len(d)), dtype=np.int32, order="F")
+    _lib.check(_lib.load().wol_general_hbonds(_lib.default_context().handle, _lib.ptr(a), len(a), _lib.ptr(d), _lib.ptr(h),
+                                              len(d), _lib.ptr(box), float(distcut), float(angcut), _lib.ptr(out)))
+    return out
+
+
+def generalhbonds_list(acceptorpos, donorpos, donorhpos, boxl, distcut, angcut):
+    """(acc_idx, don_idx) = np.where(generalhbonds(...)) without ever forming the mask (cell list on the donors)"""
+    a, d, h, box = _hb_args(acceptorpos, donorpos, donorhpos, boxl)
+    cap = max(1024, 4 * len(a))
+    while True:
+        ai = np.empty(cap, dtype=np.int32); di = np.empty(cap, dtype=np.int32); cnt = C.c_int64(0)
+        _lib.check(_lib.load().wol_general_hbonds_list(_lib.default_context().handle, _lib.ptr(a), len(a), _lib.ptr(d),
+                                                       _lib.ptr(h), len(d), _lib.ptr(box), float(distcut), float(angcut),
+                                                       cap, _lib.ptr(ai), _lib.ptr(di), C.byref(cnt)))
+        if cnt.value <= cap:
+            return ai[:cnt.value].astype(np.int64), di[:cnt.value].astype(np.int64)
+        cap = int(cnt.value)
