@@ -39,10 +39,7 @@
 #define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
 #define WOL_ROWS_TARGET ((WOL_ROWS_BLOCK * 97) / 100)
 #ifndef WOL_ROWS_WPS
-#define WOL_ROWS_WPS 4         // two blocks per CU; at 6 (three blocks, 80 VGPRs) the staging slots spill: measured slower
-#endif
-#ifndef WOL_ROWS_RELOAD
-#define WOL_ROWS_RELOAD 0
+#define WOL_ROWS_WPS 4         // a hint only: the kernel needs 78 VGPRs, so three blocks (24 waves) fit a CU anyway
 #endif
 
 // one window of candidate pairs against the lane's water (cf. wol_fast_span; bias 2^23 - 1)
@@ -79,11 +76,11 @@ __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes
 __global__ void __launch_bounds__(WOL_ROWS_BLOCK, WOL_ROWS_WPS)
 k_search_rows(FastArgs a) {
     __shared__ float4 rec[2 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)];  // pair records: array A (x0,x1,y0,y1), then array B (z0,z1,id0,id1)
+    __shared__ unsigned char rkb[2 * WOL_ROWS_CAPP];             // staged water (row order) -> rank inside its bin
     __shared__ unsigned bins[WOL_ROWS_BINW];                     // per triple: 16-bit counters, then exclusive starts
     __shared__ int rsrc[WOL_ROWS_MAXROWS * 3];                   // staged row: first slot of its three pieces
     __shared__ unsigned short rcnt[WOL_ROWS_MAXROWS * 3];        // ... and their lengths
     __shared__ int rpre[WOL_ROWS_MAXROWS + 1];                   // staged waters before the row
-    __shared__ unsigned char rowat[(2 * WOL_ROWS_CAPP) / 64 + 1];  // row holding staged water 64 * c
     __shared__ int tbase[WOL_ROWS_MAXTRIP + 1];                  // first entry of the triple (even)
     __shared__ int ttot[WOL_ROWS_MAXTRIP];
     __shared__ int qrow[WOL_ROWS_MAXRY + 2];                     // own rows -> first query number
@@ -177,15 +174,6 @@ k_search_rows(FastArgs a) {
                 rpre[nrows] = run;
                 if (run + ntrip > 2 * WOL_ROWS_CAPP) s_flag = 1;
             }
-            __builtin_amdgcn_wave_barrier();
-            if (run + ntrip <= 2 * WOL_ROWS_CAPP && lane * 64 < run) {   // <= 40 chunks of 64 staged waters
-                const int w = lane * 64;
-                int r = 0;
-#pragma unroll
-                for (int step = 64; step >= 1; step >>= 1)
-                    if (r + step < nrows && rpre[r + step] <= w) r += step;
-                rowat[lane] = (unsigned char)r;
-            }
         } else if (wave == 1) {    // own rows (centre z row of triples 1..re, the tile's own cells)
             const int c = (lane < re) ? (int)rcnt[3 * (3 * (lane + 1) + 1) + 1] : 0;
             int inc = c;
@@ -200,42 +188,25 @@ k_search_rows(FastArgs a) {
         __syncthreads();
         const bool overflow0 = s_flag != 0;
         WOL_STAMP(1);
-        // ---- phase 2: every staged water gets a thread (slot k: water tid + k * block of the tile's row-major
-        //      list; its row by binary search in rpre): all loads are issued together, then fine bin and rank
-        //      (returning LDS atomic).  The slots stay in registers for the placement pass. ----
-        constexpr int NS = (2 * WOL_ROWS_CAPP + WOL_ROWS_BLOCK - 1) / WOL_ROWS_BLOCK;
-        const int total_w = rpre[nrows];
-        int s_src[NS], s_info[NS];
-        float4 s_v[NS];
+        // ---- phase 2 (row form): one wave per staged row: fine bin and rank (returning LDS atomic) of every
+        //      water, ranks parked in LDS; small register footprint (three blocks per CU) ----
         if (!overflow0) {
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                const int w = tid + k * WOL_ROWS_BLOCK;
-                s_src[k] = -1;
-                if (w < total_w) {
-                    int r = rowat[w >> 6];           // rows are mostly longer than 64: zero to two steps
-                    while (rpre[r + 1] <= w) ++r;
-                    const int i = w - rpre[r];
-                    const int c0 = rcnt[3 * r], c1 = rcnt[3 * r + 1];
-                    const int piece = (i < c0) ? 0 : (i < c0 + c1) ? 1 : 2;
-                    s_src[k] = rsrc[3 * r + piece] + (i - (piece == 0 ? 0 : piece == 1 ? c0 : c0 + c1));
-                    s_info[k] = (r << 2) | piece;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-                if (s_src[k] >= 0) s_v[k] = sp32[s_src[k]];
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                if (s_src[k] < 0) continue;
-                const int r = s_info[k] >> 2, piece = s_info[k] & 3;
+            for (int r = wave; r < nrows; r += NW) {
                 const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f));
-                const int sc = (piece == 0) ? 0 : (piece == 1) ? (int)s_v[k].w - x0 + 1 : sxe + 1;
-                const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(s_v[k].x * inv_wf));
-                const unsigned old = atomicAdd(&bins[t * nbw + (bin >> 1)], (bin & 1) ? 0x10000u : 1u);
-                const unsigned rank = (bin & 1) ? (old >> 16) : (old & 0xFFFFu);
-                if (rank > 1023u) s_flag = 1;
-                s_info[k] = (r << 20) | (bin << 10) | (int)(rank & 1023u);   // r < 96, bin < 256, rank < 1024
+                const int c0 = rcnt[3 * r], c1 = rcnt[3 * r + 1], c2 = rcnt[3 * r + 2];
+                const int s0 = rsrc[3 * r], s1 = rsrc[3 * r + 1], s2 = rsrc[3 * r + 2];
+                const int cnt = c0 + c1 + c2, pre = rpre[r];
+                unsigned* __restrict__ bt = bins + t * nbw;
+                for (int i = lane; i < cnt; i += 64) {
+                    const int src = (i < c0) ? s0 + i : (i < c0 + c1) ? s1 + (i - c0) : s2 + (i - c0 - c1);
+                    const float4 v = sp32[src];
+                    const int sc = (i < c0) ? 0 : (i < c0 + c1) ? (int)v.w - x0 + 1 : sxe + 1;
+                    const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(v.x * inv_wf));
+                    const unsigned old = atomicAdd(&bt[bin >> 1], (bin & 1) ? 0x10000u : 1u);
+                    const unsigned rank = (bin & 1) ? (old >> 16) : (old & 0xFFFFu);
+                    if (rank > 255u) s_flag = 1;
+                    rkb[pre + i] = (unsigned char)rank;
+                }
             }
         }
         __syncthreads();
@@ -290,23 +261,26 @@ k_search_rows(FastArgs a) {
         const int dummy_p = (total_e >> 1) + WOL_ROWS_PADP - 2;
         // ---- phase 3: every water to its place (from the registers of phase 2) ----
         if (!overflow) {
-#if WOL_ROWS_RELOAD   // the coordinates are fetched again (L2-hot) instead of living in registers across the scans
-#pragma unroll
-            for (int k = 0; k < NS; ++k)
-                if (s_src[k] >= 0) s_v[k] = sp32[s_src[k]];
-#endif
-#pragma unroll
-            for (int k = 0; k < NS; ++k) {
-                if (s_src[k] < 0) continue;
-                const int r = s_info[k] >> 20, bin = (s_info[k] >> 10) & 1023, rank = s_info[k] & 1023;
+            for (int r = wave; r < nrows; r += NW) {
                 const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f)), dzk = r - 3 * t;
-                const int sc = (int)((unsigned)bin / (unsigned)WOL_XSUB);
-                const int e = tbase[t] + (int)bins16[2 * t * nbw + bin] + rank;
-                const int o = (e >> 1) * 4 + (e & 1);
-                recf[o] = ((float)sc - xc) * fx + s_v[k].x;
-                recf[o + 2] = ((float)t - yc) * fy + s_v[k].y;
-                recg[o] = (float)(dzk - 1) * fz + s_v[k].z;
-                recg[o + 2] = __uint_as_float(((unsigned)e << WOL_SLOT_BITS) | (unsigned)s_src[k]);
+                const int c0 = rcnt[3 * r], c1 = rcnt[3 * r + 1], c2 = rcnt[3 * r + 2];
+                const int s0 = rsrc[3 * r], s1 = rsrc[3 * r + 1], s2 = rsrc[3 * r + 2];
+                const int cnt = c0 + c1 + c2, pre = rpre[r];
+                const unsigned short* __restrict__ bt = bins16 + 2 * t * nbw;
+                const int tb = tbase[t];
+                const float offy = ((float)t - yc) * fy, offz = (float)(dzk - 1) * fz;
+                for (int i = lane; i < cnt; i += 64) {
+                    const int src = (i < c0) ? s0 + i : (i < c0 + c1) ? s1 + (i - c0) : s2 + (i - c0 - c1);
+                    const float4 v = sp32[src];
+                    const int sc = (i < c0) ? 0 : (i < c0 + c1) ? (int)v.w - x0 + 1 : sxe + 1;
+                    const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(v.x * inv_wf));
+                    const int e = tb + (int)bt[bin] + (int)rkb[pre + i];
+                    const int o = (e >> 1) * 4 + (e & 1);
+                    recf[o] = ((float)sc - xc) * fx + v.x;
+                    recf[o + 2] = offy + v.y;
+                    recg[o] = offz + v.z;
+                    recg[o + 2] = __uint_as_float(((unsigned)e << WOL_SLOT_BITS) | (unsigned)src);
+                }
             }
             if (tid < WOL_ROWS_PADP) {   // head-room pairs (incl. the dummy pair): nothing near
                 const int p = (total_e >> 1) + tid;
