@@ -174,7 +174,7 @@ def main():
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
                 cfg = tj["config"]
                 if cfg["waters"] == n and cfg["frames_per_step"] == F and cfg["dtype"] == args.dtype:
-                    traffic = tj["k_search_fast_hbm_bytes_per_launch"]
+                    traffic = tj["k_search_rows_hbm_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 traffic = None
         frames_total = world * args.steps * F
@@ -196,7 +196,7 @@ def main():
                        "waters": n, "frames_per_step": F, "frames_total": frames_total,
                        "sharding": "frames x%d" % world, "highCut": 10.0},
             "check": {"mean_q": float(total.mean.mean().item()), "waters_binned": waters_in_hist},
-            "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_search_rows" if args.search_rows != 0 else "k_search_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
                          "launches": int(k_launches), "avg_launch_ms": k_avg_s * 1e3,

@@ -109,7 +109,9 @@ k_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __re
 // the ~33 G/s rate of memory-side atomics), block scan in place, scatter.  Used when a batch has
 // enough frames to fill the chip with one block each and the cell table fits.
 // ---------------------------------------------------------------------------------------------
+#ifndef WOL_SORT_BLOCK
 #define WOL_SORT_BLOCK 1024
+#endif
 template <typename T>
 __global__ void __launch_bounds__(WOL_SORT_BLOCK)
 k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ cell_start,
@@ -234,7 +236,10 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
     for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) cnt[c] = 0;
     __syncthreads();
-    constexpr int U = 8;
+#ifndef WOL_SORT_U
+#define WOL_SORT_U 8
+#endif
+    constexpr int U = WOL_SORT_U;
     for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
         double y[U], z[U];
 #pragma unroll
