@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-waters", type=int, default=10000)
     ap.add_argument("--search-rows", type=int, default=-1, help="proposal kernel: 1 row-merged tiles, 0 3-D tiles (default: library default)")
+    ap.add_argument("--overlap", type=int, default=-1, help="1: sort of the next batch on a second stream beside search/finish")
+    ap.add_argument("--search-margin", type=int, default=-1, help="blocks per CU the proposal kernel leaves free")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run "
                          "(default: profiles/r01_hbm_traffic_pmc.json when the workload matches it)")
@@ -123,6 +125,11 @@ def main():
         ctx.set_option("path", args.path)
     if args.search_rows >= 0:
         ctx.set_option("search_rows", args.search_rows)
+    if args.overlap >= 0:
+        ctx.set_option("overlap", args.overlap)
+        ctx.set_option("inputs_resident", 1)
+    if args.search_margin >= 0:
+        ctx.set_option("search_margin", args.search_margin)
 
     total_steps = args.warmup + args.steps
     # every step owns its frames; generated (untimed) up front so the timed region only reads HBM

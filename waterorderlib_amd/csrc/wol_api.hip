@@ -104,6 +104,7 @@ struct wol_ctx {
     bool overlap = false;  // measured on MI355X: the sort and the search contend for the same CU slots and
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
+    int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
     PinBuf grids_host;
@@ -533,7 +534,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
 #endif
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = 0;
-            if (rows_kernel) WOL_TRY(resident_grid(c, k_search_rows, WOL_ROWS_BLOCK, 0, ftotal, &fgrid, 0));
+            if (rows_kernel) WOL_TRY(resident_grid(c, k_search_rows, WOL_ROWS_BLOCK, 0, ftotal, &fgrid, c->search_margin));
             else WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
@@ -835,6 +836,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->inputs_resident = value != 0.0;
     } else if (k == "search_rows") {
         c->search_rows = value != 0.0;
+    } else if (k == "search_margin") {
+        c->search_margin = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0.0;
     } else if (k == "lds_sort") {

@@ -386,6 +386,19 @@ __device__ __forceinline__ void wol_fix_split(double x, long long* hi, long long
     *lo = (long long)((t - fl) * 1099511627776.0);  // 2^40
 }
 
+// the same split without the emulated double -> int64 conversions: adding 1.5 * 2^52 to an integer-valued double
+// of magnitude < 2^51 leaves 2^51 + x in the mantissa field
+__device__ __forceinline__ long long wol_small_int_of(double x) {
+    const long long b = __double_as_longlong(x + 6755399441055744.0);
+    return (b & 0x000FFFFFFFFFFFFFll) - 0x0008000000000000ll;
+}
+__device__ __forceinline__ void wol_fix_split_fast(double x, long long* hi, long long* lo) {
+    const double t = x * 1073741824.0;            // 2^30, exact scaling; |t| < 2^34 for any q or q^2
+    const double fl = floor(t);
+    *hi = wol_small_int_of(fl);
+    *lo = wol_small_int_of(floor((t - fl) * 1099511627776.0));  // 2^40: truncation of a non-negative value
+}
+
 // rare paths: one lane adds its water straight to the frame's accumulators
 __device__ __forceinline__ void wol_stat_add_lane(const QOut& o, int f, double q) {
     if (!o.stat) return;

@@ -570,35 +570,33 @@ k_finish_fast(FastArgs a) {
             const double4 mev = sp[s];
             const double c[3] = {mev.x, mev.y, mev.z};
             const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
-            double vx[4], vy[4], vz[4], dist[4];
+            // The minimum-image vectors d themselves stand in for the reference's (apos + d) - apos (wp:372-373) and
+            // for tetraCosAng's second re-image: they differ by rounding of order ulp(apos), 1e-15 relative, which q
+            // tolerates (|dq| < 1e-14) and the distance bins do not notice except on a bin edge -- there the
+            // reference's chain is evaluated (below).  One rsqrt per neighbour gives both its norm and its distance.
+            double dx[4], dy[4], dz[4], rn[4], dist[4];
             double dmax = 0.0, emax = 0.0;
             bool all_in = true;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const double dx = wol_minimg1(nb[k].x - c[0], g.box.L[0], g.box.ib[0]);   // waterlib.f90:733-735
-                const double dy = wol_minimg1(nb[k].y - c[1], g.box.L[1], g.box.ib[1]);
-                const double dz = wol_minimg1(nb[k].z - c[2], g.box.L[2], g.box.ib[2]);
-                const double d2 = wol_sumsq(dx, dy, dz);
+                dx[k] = wol_minimg1(nb[k].x - c[0], g.box.L[0], g.box.ib[0]);   // waterlib.f90:733-735
+                dy[k] = wol_minimg1(nb[k].y - c[1], g.box.L[1], g.box.ib[1]);
+                dz[k] = wol_minimg1(nb[k].z - c[2], g.box.L[2], g.box.ib[2]);
+                const double d2 = wol_sumsq(dx[k], dy[k], dz[k]);
                 all_in = all_in && (d2 > 0.0) && (d2 <= a.highsq);
-                const double px = c[0] + dx, py = c[1] + dy, pz = c[2] + dz;              // reimage (wp:372)
-                vx[k] = px - c[0]; vy[k] = py - c[1]; vz[k] = pz - c[2];                  // thisPos - apos (wp:373)
-                dist[k] = sqrt(wol_sumsq(vx[k], vy[k], vz[k]));
+                rn[k] = rsqrt(d2);
+                dist[k] = d2 * rn[k];
                 dmax = fmax(dmax, dist[k]);
-                emax = fmax(emax, fmax(fabs(vx[k]) * g.box.ib[0], fmax(fabs(vy[k]) * g.box.ib[1], fabs(vz[k]) * g.box.ib[2])));
+                emax = fmax(emax, fmax(fabs(dx[k]) * g.box.ib[0], fmax(fabs(dy[k]) * g.box.ib[1], fabs(dz[k]) * g.box.ib[2])));
             }
-            const double rg = wol_guaranteed_radius(c, g, a.rows);
+            // every neighbour inside the smallest cell width is inside the guaranteed radius: the walls only matter beyond
+            const double cwmin = fmin(g.cw[0], fmin(g.cw[1], g.cw[2]));
+            const double rg = (dmax > cwmin - 1e-4) ? wol_guaranteed_radius(c, g, a.rows) : cwmin;
             const double d3s = (dmax * dmax) * g.S;
-            // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity, so the
-            // vectors CosAngle3 sees are exactly (apos + v) - apos
+            // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity
             if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)eps_u || !(emax < 0.49)) {
                 slow = true;
             } else {
-                double wx[4], wy[4], wz[4], rn[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    wx[k] = (c[0] + vx[k]) - c[0]; wy[k] = (c[1] + vy[k]) - c[1]; wz[k] = (c[2] + vz[k]) - c[2];
-                    rn[k] = rsqrt(wol_sumsq(wx[k], wy[k], wz[k]));
-                }
                 // the six terms are summed in ascending order of their values: the result must not depend
                 // on the order in which the proposal lists the neighbours (which can follow the arrival
                 // order of waters inside a cell when two fp32 keys tie)
@@ -609,7 +607,7 @@ k_finish_fast(FastArgs a) {
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = i + 1; j < 4; ++j) {
-                            const double dot = (wx[i] * wx[j] + wy[i] * wy[j]) + wz[i] * wz[j];
+                            const double dot = (dx[i] * dx[j] + dy[i] * dy[j]) + dz[i] * dz[j];
                             const double cs_ = fmin(1.0, fmax(-1.0, dot * (rn[i] * rn[j]))) + (1.0 / 3.0);
                             tm[m++] = cs_ * cs_;
                         }
@@ -630,8 +628,8 @@ k_finish_fast(FastArgs a) {
                     if (a.out.q) a.out.q[orow] = q;
                     if (a.out.q32) a.out.q32[orow] = (float)q;
                 }
-                wol_fix_split(q, &acc_h, &acc_l);
-                wol_fix_split(q * q, &acc_h2, &acc_l2);
+                wol_fix_split_fast(q, &acc_h, &acc_l);
+                wol_fix_split_fast(q * q, &acc_h2, &acc_l2);
                 if (lds_qh) {
                     const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
                     if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
@@ -639,11 +637,14 @@ k_finish_fast(FastArgs a) {
                 if (lds_dh) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal and
-                        // take the true division only when the product sits on an integer
+                        // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal; when the
+                        // product sits on an integer, the reference's distance and the true division decide
                         const double tq = dist[k] * dinv;
                         double cb = ceil(tq);
-                        if (fabs(tq - rint(tq)) < 1e-9 * tq) cb = ceil(dist[k] / a.out.dbinwidth);
+                        if (fabs(tq - rint(tq)) < 1e-9 * tq) {
+                            const double vx = (c[0] + dx[k]) - c[0], vy = (c[1] + dy[k]) - c[1], vz = (c[2] + dz[k]) - c[2];
+                            cb = ceil(sqrt(wol_sumsq(vx, vy, vz)) / a.out.dbinwidth);
+                        }
                         if (cb >= 1.0 && cb <= (double)a.out.dbins) atomicAdd(&lds_dh[(int)cb - 1], 1);
                     }
                 }
