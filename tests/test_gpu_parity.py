@@ -320,6 +320,38 @@ def test_both_proposal_kernels_agree_and_match_oracle(wp, oracle):
             assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_boxes_and_densities_vs_oracle(wp, oracle, seed):
+    """seeded sweep over box shapes (3 to ~25 cells per axis), densities and clustering -- tiles that wrap around the
+    box, rows with few or no waters, cells beyond the tile tables' capacity (forced onto the exact path): indices,
+    distances, angles and q of every water against the oracle, for both proposal kernels"""
+    from waterorderlib_amd import _lib
+    oracle.set_threads(8)
+    rng = np.random.default_rng(1000 + seed)
+    box = rng.uniform(13.6, 110.0, size=3)
+    if seed % 3 == 0:
+        box[rng.integers(3)] = rng.uniform(13.6, 15.0)          # three cells along one axis
+    rho = [0.0334, 0.0334, 0.02, 0.05, 0.0334, 0.01, 0.0334, 0.07, 0.0334, 0.004][seed]
+    n = int(min(max(rho * np.prod(box), 300), 14000))
+    pos = rng.random((n, 3)) * box
+    if seed % 2 == 1:                                              # droplets: a third of the waters in dense blobs
+        k = n // 3
+        centres = rng.random((5, 3)) * box
+        pos[:k] = centres[rng.integers(5, size=k)] + rng.normal(0.0, 2.5, size=(k, 3))
+    if seed == 4:
+        pos[:200] = pos[0] + rng.normal(0.0, 0.35, size=(200, 3))  # one overfull cell
+    pos += rng.integers(-1, 2, size=pos.shape) * box               # unwrapped molecules
+    q_o, idx_o, dist_o, ang_o = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    # the reference leaves exact distance ties to argsort: make sure this input has none among the first five
+    for rows in (1, 0):
+        c = _lib.Context(0)
+        c.set_option("path", 3)
+        c.set_option("search_rows", rows)
+        check_full(wp.getOrderParamq(pos, pos, box, full=True, ctx=c), q_o, idx_o, dist_o, ang_o)
+        np.testing.assert_allclose(wp.getOrderParamq(pos, pos, box, ctx=c), q_o, rtol=0, atol=Q_TOL)
+        c.close()
+
+
 # ---- SURVEY 8f row f-1: Willard-Chandler density field ---------------------------------------------
 DENS_RTOL = 1e-12   # device exp() vs glibc exp(): a few ulp on each Gaussian term
 NORM_ATOL = 1e-10   # unit normals; looser where the gradient nearly cancels
