@@ -297,30 +297,90 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     }
 }
 
+#define WOL_L2_CAP 128        // waters of a row sorted through registers and LDS (two per lane); longer rows: direct form
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
               const double4* __restrict__ tmp, int n, int* __restrict__ cell_start,
               double4* __restrict__ sorted, float4* __restrict__ sorted32) {
     __shared__ int cnt_all[(WOL_BLOCK / 64) * WOL_L2_MAXNX];
+    __shared__ double4 st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];   // the row in cell order, written out linearly:
+    __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
     const int f = blockIdx.y, cz = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const FrameGrid& g = grids[f];
     const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
     if (cz >= nz) return;
     int* cnt = cnt_all + wave * WOL_L2_MAXNX;
+    double4* st64 = st64_all + wave * WOL_L2_CAP;
+    float4* st32 = st32_all + wave * WOL_L2_CAP;
     const int* ro = row_off + (int64_t)f * ro_stride;
     const double4* __restrict__ in = tmp + (int64_t)f * n;
     double4* __restrict__ so = sorted + (int64_t)f * n;
     float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
+    const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
     for (int cy = wave; cy < ny; cy += WOL_BLOCK / 64) {  // one wave per row, no block-level barriers
         const int row = cz * ny + cy;
         const int b = ro[row], e = ro[row + 1];
+        int* __restrict__ cs = cell_start + g.cell_base + (int64_t)row * nx;
         for (int c = lane; c < nx; c += 64) cnt[c] = 0;
         __builtin_amdgcn_wave_barrier();
+        if (e - b <= WOL_L2_CAP) {
+            // ---- the usual row: read once (two waters per lane stay in registers), rank = returning LDS atomic ----
+            double4 v[2];
+            float4 w[2];
+            int cxs[2], rank[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = b + lane + 64 * u;
+                cxs[u] = -1;
+                if (i < e) {
+                    v[u] = in[i];
+                    double ux = v[u].x * g.box.ib[0]; ux -= floor(ux);
+                    double uy = v[u].y * g.box.ib[1]; uy -= floor(uy);
+                    double uz = v[u].z * g.box.ib[2]; uz -= floor(uz);
+                    int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);  // as wol_cell_coord
+                    cxs[u] = cx;
+                    w[u].x = (float)((ux * (double)nx - (double)cx) * sx);
+                    w[u].y = (float)((uy * (double)ny - (double)cy) * sy);
+                    w[u].z = (float)((uz * (double)nz - (double)cz) * sz);
+                    w[u].w = (float)cx;  // cell number along x (k_search_rows builds tile coordinates from it)
+                    rank[u] = atomicAdd(&cnt[cx], 1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            {   // exclusive scan over the row's cells (nx <= 128: two per lane), cell_start of the row
+                const int c0 = 2 * lane, c1 = 2 * lane + 1;
+                const int v0 = c0 < nx ? cnt[c0] : 0, v1 = c1 < nx ? cnt[c1] : 0;
+                int inc = v0 + v1;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += t;
+                }
+                const int ex = inc - (v0 + v1);
+                if (c0 < nx) { cnt[c0] = ex; cs[c0] = b + ex; }
+                if (c1 < nx) { cnt[c1] = ex + v0; cs[c1] = b + ex + v0; }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (cxs[u] >= 0) {
+                    const int d = cnt[cxs[u]] + rank[u];
+                    st64[d] = v[u];
+                    st32[d] = w[u];
+                }
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < e - b; i += 64) {
+                so[b + i] = st64[i];
+                if (so32) so32[b + i] = st32[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
+        // ---- long rows: count, scan, scatter straight into the final arrays ----
         for (int i = b + lane; i < e; i += 64)
             atomicAdd(&cnt[wol_cell_coord(in[i].x, g.box.ib[0], nx, nullptr)], 1);
         __builtin_amdgcn_wave_barrier();
-        // exclusive scan over the row's cells (nx <= 128: two per lane), cell_start of the row
         {
             const int c0 = 2 * lane, c1 = 2 * lane + 1;
             const int v0 = c0 < nx ? cnt[c0] : 0, v1 = c1 < nx ? cnt[c1] : 0;
@@ -331,12 +391,11 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
                 if (lane >= off) inc += t;
             }
             const int ex = b + inc - (v0 + v1);
-            int* __restrict__ cs = cell_start + g.cell_base + (int64_t)row * nx;
             if (c0 < nx) { cnt[c0] = ex; cs[c0] = ex; }
             if (c1 < nx) { cnt[c1] = ex + v0; cs[c1] = ex + v0; }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int i = b + lane; i < e; i += 64) {  // second read: the row bucket is a few KB, L1-hot
+        for (int i = b + lane; i < e; i += 64) {
             const double4 v = in[i];
             double ux = v.x * g.box.ib[0]; ux -= floor(ux);
             double uy = v.y * g.box.ib[1]; uy -= floor(uy);
@@ -346,10 +405,10 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             so[dst] = v;
             if (so32) {
                 float4 w;
-                w.x = (float)((ux * (double)nx - (double)cx) * g.cw[0] * (double)g.scale);
-                w.y = (float)((uy * (double)ny - (double)cy) * g.cw[1] * (double)g.scale);
-                w.z = (float)((uz * (double)nz - (double)cz) * g.cw[2] * (double)g.scale);
-                w.w = (float)cx;  // cell number along x (k_search_rows builds tile coordinates from it)
+                w.x = (float)((ux * (double)nx - (double)cx) * sx);
+                w.y = (float)((uy * (double)ny - (double)cy) * sy);
+                w.z = (float)((uz * (double)nz - (double)cz) * sz);
+                w.w = (float)cx;
                 so32[dst] = w;
             }
         }

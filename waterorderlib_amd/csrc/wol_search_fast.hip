@@ -559,15 +559,18 @@ k_finish_fast(FastArgs a) {
         if (g.maxshell < 0) continue;  // all-pairs frame
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
         const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
+        // key, proposal and own coordinates are fetched together (one round trip), the neighbours in a second one
         const int kd3 = live ? a.prop_key[w] : 0;
+        const int4 pr_all = a.prop[w];
+        const double4 mev_all = sp[s];
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
         if constexpr (LEAN) { if (live && !slow) {
             // ---- lean path (trajectory mode: q, histograms, no per-neighbour outputs): the four
             //      proposed neighbours are certified and q is formed from their min-image vectors in
             //      proposal order -- no ranking, no second re-image, shared norms ----
-            const int4 pr = a.prop[w];
-            const double4 mev = sp[s];
+            const int4 pr = pr_all;
+            const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
             const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
             // The minimum-image vectors d themselves stand in for the reference's (apos + d) - apos (wp:372-373) and
@@ -650,8 +653,8 @@ k_finish_fast(FastArgs a) {
                 }
             }
         } } else if (live && !slow) {
-            const int4 pr = a.prop[w];
-            const double4 mev = sp[s];
+            const int4 pr = pr_all;
+            const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
             const double4 n0 = sp[pr.x], n1 = sp[pr.y], n2 = sp[pr.z], n3 = sp[pr.w];
             Top4 t;
