@@ -211,7 +211,7 @@ def main():
                          "tile_density_level": dens_level,
                          "alg_bytes_per_launch": alg_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 of the one-GPU run only
             pos_host = batches[args.warmup][0].to(torch.float64).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(pos_host, box, min(args.cpu_sample_waters, n), len(os.sched_getaffinity(0)))
         print(json.dumps(out))

@@ -39,7 +39,7 @@
 #define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
 #define WOL_ROWS_TARGET ((WOL_ROWS_BLOCK * 97) / 100)
 #ifndef WOL_ROWS_WPS
-#define WOL_ROWS_WPS 4         // a hint only: the kernel needs 78 VGPRs, so three blocks (24 waves) fit a CU anyway
+#define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
 #endif
 
 // one window of candidate pairs against the lane's water (cf. wol_fast_span; bias 2^23 - 1)
@@ -197,10 +197,15 @@ k_search_rows(FastArgs a) {
                 const int s0 = rsrc[3 * r], s1 = rsrc[3 * r + 1], s2 = rsrc[3 * r + 2];
                 const int cnt = c0 + c1 + c2, pre = rpre[r];
                 unsigned* __restrict__ bt = bins + t * nbw;
+                // piece offsets folded into one add per piece: src = i + d_piece (selects, no branches: the loads of a
+                // row's iterations must not wait for one another)
+                const int d0 = s0, d1 = s1 - c0, d2 = s2 - c0 - c1;
                 for (int i = lane; i < cnt; i += 64) {
-                    const int src = (i < c0) ? s0 + i : (i < c0 + c1) ? s1 + (i - c0) : s2 + (i - c0 - c1);
+                    const bool p0 = i < c0, p2 = i >= c0 + c1;
+                    const int src = i + (p0 ? d0 : p2 ? d2 : d1);
                     const float4 v = sp32[src];
-                    const int sc = (i < c0) ? 0 : (i < c0 + c1) ? (int)v.w - x0 + 1 : sxe + 1;
+                    // (masks instead of selects: the compiler would otherwise fetch v.w in a second, conditional load)
+                    const int sc = (((int)v.w - x0 + 1) & ((p0 || p2) ? 0 : -1)) | (p2 ? sxe + 1 : 0);
                     const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(v.x * inv_wf));
                     const unsigned old = atomicAdd(&bt[bin >> 1], (bin & 1) ? 0x10000u : 1u);
                     const unsigned rank = (bin & 1) ? (old >> 16) : (old & 0xFFFFu);
@@ -269,10 +274,13 @@ k_search_rows(FastArgs a) {
                 const unsigned short* __restrict__ bt = bins16 + 2 * t * nbw;
                 const int tb = tbase[t];
                 const float offy = ((float)t - yc) * fy, offz = (float)(dzk - 1) * fz;
+                const int d0 = s0, d1 = s1 - c0, d2 = s2 - c0 - c1;
                 for (int i = lane; i < cnt; i += 64) {
-                    const int src = (i < c0) ? s0 + i : (i < c0 + c1) ? s1 + (i - c0) : s2 + (i - c0 - c1);
+                    const bool p0 = i < c0, p2 = i >= c0 + c1;
+                    const int src = i + (p0 ? d0 : p2 ? d2 : d1);
                     const float4 v = sp32[src];
-                    const int sc = (i < c0) ? 0 : (i < c0 + c1) ? (int)v.w - x0 + 1 : sxe + 1;
+                    // (masks instead of selects: the compiler would otherwise fetch v.w in a second, conditional load)
+                    const int sc = (((int)v.w - x0 + 1) & ((p0 || p2) ? 0 : -1)) | (p2 ? sxe + 1 : 0);
                     const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(v.x * inv_wf));
                     const int e = tb + (int)bt[bin] + (int)rkb[pre + i];
                     const int o = (e >> 1) * 4 + (e & 1);
