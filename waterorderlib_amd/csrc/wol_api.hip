@@ -104,6 +104,7 @@ struct wol_ctx {
     bool overlap = false;  // measured on MI355X: the sort and the search contend for the same CU slots and
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
+    size_t sort_rows_lds_set = 0;
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
@@ -459,8 +460,16 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             const int ro_stride = nrow_max + 1;
             WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
             WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
-            hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), 0, ss, fv,
-                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>());
+            const size_t l1_lds = wol_sort_rows_lds(nrow_max);
+            if (l1_lds > c->sort_rows_lds_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wol_sort_rows_lds(WOL_L1_MAXROWS)));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wol_sort_rows_lds(WOL_L1_MAXROWS)));
+                c->sort_rows_lds_set = wol_sort_rows_lds(WOL_L1_MAXROWS);
+            }
+            hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), l1_lds, ss, fv,
+                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
             hipLaunchKernelGGL(k_sort_in_row, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
                                c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
                                S.sorted.as<double4>(), s32);

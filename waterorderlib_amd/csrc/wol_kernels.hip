@@ -222,19 +222,35 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
 //           by cx with per-wave LDS counters straight into the final arrays; consecutive rows are
 //           consecutive in the output, so those writes stream too.
 // ---------------------------------------------------------------------------------------------
-#define WOL_L1_MAXROWS 4096   // nz * ny rows counted in LDS by level 1
+#define WOL_L1_MAXROWS 4080   // nz * ny rows counted in LDS by level 1 (three tables + the chunk staging within 160 KB)
 #define WOL_L2_MAXNX 128      // cells of a row handled by one wave of level 2
+#define WOL_L1_CHUNK 3            // waters per thread and chunk of level 1 (chunk = 3 * 1024 waters: 96 KB of staging)
+// dynamic LDS of k_sort_rows for a frame with nrow cell rows
+__host__ __device__ inline size_t wol_sort_rows_lds(int nrow) {
+    return (size_t)WOL_L1_CHUNK * WOL_SORT_BLOCK * (sizeof(double4) + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
+}
 template <typename T>
 __global__ void __launch_bounds__(WOL_SORT_BLOCK)
 k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
-            double4* __restrict__ tmp) {
-    __shared__ int cnt[WOL_L1_MAXROWS + 1];
+            double4* __restrict__ tmp, int nrow_cap) {
+    // A lane's 32-byte store to its water's row bucket is a transaction of its own (64 per wave instruction): the
+    // scatter alone cost 0.23 ms of 0.61.  So a chunk of 3072 waters is first ordered by row inside LDS (returning
+    // atomic = rank inside the row, a scan over the rows) and then written out in that order: a row's ~3 waters of
+    // the chunk are consecutive lanes writing consecutive addresses.
+    extern __shared__ double4 lds_sort_rows[];
+    constexpr int C = WOL_L1_CHUNK * WOL_SORT_BLOCK;
+    double4* stage = lds_sort_rows;                                 // [C] the chunk in row order
+    int* dest = reinterpret_cast<int*>(stage + C);                   // [C] its slots in tmp[]
+    int* cnt = dest + C;                                             // [nrow + 1] row cursors in tmp[]
+    int* icnt = cnt + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
+    int* delta = icnt + (nrow_cap + 1);                              // [nrow + 1] cursor - start of the row in this chunk
     __shared__ int part[WOL_SORT_BLOCK];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    __shared__ int wtot[WOL_SORT_BLOCK / 64];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameGrid& g = grids[f];
     const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
     const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
-    for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) cnt[c] = 0;
+    for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) { cnt[c] = 0; icnt[c] = 0; }
     __syncthreads();
 #ifndef WOL_SORT_U
 #define WOL_SORT_U 8
@@ -272,28 +288,67 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
     __syncthreads();
     double4* __restrict__ out = tmp + (int64_t)f * fv.n;
-    for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
-        double x[U], y[U], z[U];
+    for (int c0 = 0; c0 < fv.n; c0 += C) {
+        const int cn = min(C, fv.n - c0);
+        // (1) the chunk's waters: row and rank inside the row
+        double x[WOL_L1_CHUNK], y[WOL_L1_CHUNK], z[WOL_L1_CHUNK];
+        int row[WOL_L1_CHUNK], lr[WOL_L1_CHUNK];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * WOL_SORT_BLOCK;
+        for (int u = 0; u < WOL_L1_CHUNK; ++u) {
+            const int i = c0 + u * WOL_SORT_BLOCK + tid;
+            row[u] = -1;
             if (i < fv.n) {
                 const T* p = base + (int64_t)i * fv.atom_stride;
                 x[u] = (double)p[0]; y[u] = (double)p[1]; z[u] = (double)p[2];
             }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * WOL_SORT_BLOCK;
+        for (int u = 0; u < WOL_L1_CHUNK; ++u) {
+            const int i = c0 + u * WOL_SORT_BLOCK + tid;
             if (i < fv.n) {
-                const int row = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
-                const int pos = atomicAdd(&cnt[row], 1);
-                double4 v;
-                v.x = x[u]; v.y = y[u]; v.z = z[u];
-                v.w = __longlong_as_double((long long)i);
-                out[pos] = v;
+                row[u] = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
+                lr[u] = atomicAdd(&icnt[row[u]], 1);
             }
         }
+        __syncthreads();
+        // (2) starts of the rows inside the chunk (thread t owns rows [sb, se)); cursors advance by the chunk's counts
+        int s2 = 0;
+        for (int k = sb; k < se; ++k) s2 += icnt[k];
+        int inc = s2;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int before = 0;
+        for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+        int st = before + inc - s2;
+        for (int k = sb; k < se; ++k) {
+            const int v = icnt[k];
+            icnt[k] = st;               // start of row k in the staged chunk
+            delta[k] = cnt[k] - st;     // slot in tmp[] = staged position + delta
+            cnt[k] += v;
+            st += v;
+        }
+        __syncthreads();
+        // (3) into the staging area in row order
+#pragma unroll
+        for (int u = 0; u < WOL_L1_CHUNK; ++u)
+            if (row[u] >= 0) {
+                const int k = icnt[row[u]] + lr[u];
+                double4 v;
+                v.x = x[u]; v.y = y[u]; v.z = z[u];
+                v.w = __longlong_as_double((long long)(c0 + u * WOL_SORT_BLOCK + tid));
+                stage[k] = v;
+                dest[k] = k + delta[row[u]];
+            }
+        __syncthreads();
+        // (4) out, in staged order; the owners clear the chunk counters for the next round
+        for (int k = tid; k < cn; k += WOL_SORT_BLOCK) out[dest[k]] = stage[k];
+        for (int k = sb; k < se; ++k) icnt[k] = 0;
+        __syncthreads();
     }
 }
 
