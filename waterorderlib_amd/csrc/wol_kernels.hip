@@ -288,23 +288,36 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
     __syncthreads();
     double4* __restrict__ out = tmp + (int64_t)f * fv.n;
+    // the next chunk's coordinates are fetched while the current one goes through LDS (one block per CU: nothing
+    // else would cover the load latency)
+    double nx_[WOL_L1_CHUNK], ny_[WOL_L1_CHUNK], nz_[WOL_L1_CHUNK];
+#pragma unroll
+    for (int u = 0; u < WOL_L1_CHUNK; ++u) {
+        const int i = u * WOL_SORT_BLOCK + tid;
+        if (i < fv.n) {
+            const T* p = base + (int64_t)i * fv.atom_stride;
+            nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
+        }
+    }
     for (int c0 = 0; c0 < fv.n; c0 += C) {
         const int cn = min(C, fv.n - c0);
         // (1) the chunk's waters: row and rank inside the row
         double x[WOL_L1_CHUNK], y[WOL_L1_CHUNK], z[WOL_L1_CHUNK];
         int row[WOL_L1_CHUNK], lr[WOL_L1_CHUNK];
 #pragma unroll
+        for (int u = 0; u < WOL_L1_CHUNK; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
+#pragma unroll
         for (int u = 0; u < WOL_L1_CHUNK; ++u) {
-            const int i = c0 + u * WOL_SORT_BLOCK + tid;
-            row[u] = -1;
+            const int i = c0 + C + u * WOL_SORT_BLOCK + tid;
             if (i < fv.n) {
                 const T* p = base + (int64_t)i * fv.atom_stride;
-                x[u] = (double)p[0]; y[u] = (double)p[1]; z[u] = (double)p[2];
+                nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
             }
         }
 #pragma unroll
         for (int u = 0; u < WOL_L1_CHUNK; ++u) {
             const int i = c0 + u * WOL_SORT_BLOCK + tid;
+            row[u] = -1;
             if (i < fv.n) {
                 row[u] = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
                 lr[u] = atomicAdd(&icnt[row[u]], 1);
