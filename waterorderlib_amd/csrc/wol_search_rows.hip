@@ -53,10 +53,16 @@ __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes
     const wol_f2 bias = {8388607.0f, 8388607.0f};
     int off = pb * 16;
     const int end = (pb + np) * 16;
-    int tmax_np = np;
-#pragma unroll
-    for (int sh = 32; sh >= 1; sh >>= 1) tmax_np = max(tmax_np, __shfl_xor(tmax_np, sh, 64));
-    const int T = __builtin_amdgcn_readfirstlane(tmax_np);
+    // wave-uniform trip count = the longest window of the wave: a DPP reduction (shifts inside the rows of 16, two
+    // row broadcasts, lane 63 holds the maximum) instead of six LDS-permute round trips; np >= 0 and all 64 lanes active
+    int m = np;
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x111, 0xf, 0xf, false));  // row_shr:1
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x112, 0xf, 0xf, false));  // row_shr:2
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x114, 0xf, 0xf, false));  // row_shr:4
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x118, 0xf, 0xf, false));  // row_shr:8
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    const int T = __builtin_amdgcn_readlane(m, 63);
     for (int t = 0; t < T; ++t, off += 16) {
         const int o = (off < end) ? off : dummy_off;
         const float4 a = *reinterpret_cast<const float4*>(rec_bytes + o);
@@ -324,17 +330,29 @@ k_search_rows(FastArgs a) {
                 const wol_f2 xi = {mx, mx}, yi = {my, my}, zi = {mz, mz};
                 const unsigned tmaxbits = __float_as_uint(g.tmax);
                 unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
+                // the three windows as (pairs << 16 | first pair); each lane sweeps its longest first: the loops' trip
+                // counts are wave maxima, and maxima of sorted lengths add up to less (38.3 instead of 40.5 pairs)
+                unsigned win[3];
 #pragma unroll
                 for (int dt = 0; dt < 3; ++dt) {
                     const int t = j + dt;
                     const unsigned short* __restrict__ bt = bins16 + 2 * t * nbw;
                     const int lo = tbase[t] + (int)bt[b - WOL_XSUB], hi = tbase[t] + (int)bt[b + WOL_XSUB + 1];
                     const int pb = lo >> 1, pe = live ? (hi + 1) >> 1 : pb;
+                    win[dt] = ((unsigned)(pe - pb) << 16) | (unsigned)pb;
+                }
+                {
+                    const unsigned a01 = max(win[0], win[1]), b01 = min(win[0], win[1]);
+                    const unsigned c2 = max(b01, win[2]);
+                    win[2] = min(b01, win[2]); win[0] = max(a01, c2); win[1] = min(a01, c2);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
 #ifdef WOL_EXP_NO_SWEEP   // ablation build: timing only, results are wrong
-                    k0 ^= (unsigned)(pb + pe);
+                    k0 ^= win[dt];
 #else
-                    wol_rows_span(reinterpret_cast<const char*>(rec), pb, pe - pb, dummy_p * 16, xi, yi, zi, tmaxbits,
-                                  k0, k1, k2, k3, k4);
+                    wol_rows_span(reinterpret_cast<const char*>(rec), (int)(win[dt] & 0xFFFFu), (int)(win[dt] >> 16), dummy_p * 16,
+                                  xi, yi, zi, tmaxbits, k0, k1, k2, k3, k4);
 #endif
                 }
                 const unsigned d3 = k3 >> WOL_ID_BITS, d4 = k4 >> WOL_ID_BITS;
