@@ -88,7 +88,6 @@ k_search_rows(FastArgs a) {
     __shared__ unsigned short rcnt[WOL_ROWS_MAXROWS * 3];        // ... and their lengths
     __shared__ int rpre[WOL_ROWS_MAXROWS + 1];                   // staged waters before the row
     __shared__ int tbase[WOL_ROWS_MAXTRIP + 1];                  // first entry of the triple (even)
-    __shared__ int ttot[WOL_ROWS_MAXTRIP];
     __shared__ int qrow[WOL_ROWS_MAXRY + 2];                     // own rows -> first query number
     __shared__ int s_flag;
     const int tid = threadIdx.x;
@@ -190,6 +189,28 @@ k_search_rows(FastArgs a) {
             }
             if (lane < re) qrow[lane + 1] = inc;
             if (lane == 0) qrow[0] = 0;
+        } else if (wave == 2) {    // first entry of every triple (even): its size is known from the row table already
+            int tot = 0;
+            if (lane < ntrip)
+#pragma unroll
+                for (int u = 0; u < 9; ++u) tot += (int)rcnt[9 * lane + u];
+            const int len = (tot + 1) & ~1;
+            int inc = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += v;
+            }
+            if (lane < ntrip) {
+                tbase[lane] = inc - len;
+                if ((tot & 1) && inc <= 2 * WOL_ROWS_CAPP) {   // complete the triple's last pair with a far-away dummy
+                    const int e = inc - len + tot;
+                    const int o = (e >> 1) * 4 + 1;
+                    recf[o] = 1.0e7f; recf[o + 2] = 1.0e7f; recg[o] = 1.0e7f;
+                    recg[o + 2] = __uint_as_float((unsigned)e << WOL_SLOT_BITS);
+                }
+            }
+            if (lane == ntrip - 1) tbase[ntrip] = inc;
         }
         __syncthreads();
         const bool overflow0 = s_flag != 0;
@@ -243,27 +264,6 @@ k_search_rows(FastArgs a) {
             for (int u = 0; u < 4; ++u) { st[u] = (4 * lane + u < nb) ? run : tot; run += c[u]; }   // bin nb holds the total
             if (mine) bt[2 * lane] = (unsigned)st[0] | ((unsigned)st[1] << 16);
             if (2 * lane + 1 < nbw) bt[2 * lane + 1] = (unsigned)st[2] | ((unsigned)st[3] << 16);
-            if (lane == 63) ttot[t] = tot;
-        }
-        __syncthreads();
-        if (wave == 0) {           // triples start on even entries
-            const int len = (lane < ntrip) ? (ttot[lane] + 1) & ~1 : 0;
-            int inc = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += v;
-            }
-            if (lane < ntrip) {
-                tbase[lane] = inc - len;
-                if (ttot[lane] & 1) {      // complete the triple's last pair with a far-away dummy
-                    const int e = inc - len + ttot[lane];
-                    const int o = (e >> 1) * 4 + 1;
-                    recf[o] = 1.0e7f; recf[o + 2] = 1.0e7f; recg[o] = 1.0e7f;
-                    recg[o + 2] = __uint_as_float((unsigned)e << WOL_SLOT_BITS);
-                }
-            }
-            if (lane == ntrip - 1) tbase[ntrip] = inc;
         }
         __syncthreads();
         const bool overflow = s_flag != 0;
