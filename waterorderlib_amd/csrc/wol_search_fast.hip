@@ -582,16 +582,21 @@ k_finish_fast(FastArgs a) {
             bool all_in = true;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                dx[k] = wol_minimg1(nb[k].x - c[0], g.box.L[0], g.box.ib[0]);   // waterlib.f90:733-735
-                dy[k] = wol_minimg1(nb[k].y - c[1], g.box.L[1], g.box.ib[1]);
-                dz[k] = wol_minimg1(nb[k].z - c[2], g.box.L[2], g.box.ib[2]);
+                // waterlib.f90:733-735 with rint for anint: they differ only on exact half-integers, i.e. a neighbour
+                // at exactly half a box length, which the emax test below sends to the exact path anyway
+                const double ex = nb[k].x - c[0], ey = nb[k].y - c[1], ez = nb[k].z - c[2];
+                dx[k] = ex - g.box.L[0] * rint(ex * g.box.ib[0]);
+                dy[k] = ey - g.box.L[1] * rint(ey * g.box.ib[1]);
+                dz[k] = ez - g.box.L[2] * rint(ez * g.box.ib[2]);
                 const double d2 = wol_sumsq(dx[k], dy[k], dz[k]);
                 all_in = all_in && (d2 > 0.0) && (d2 <= a.highsq);
                 rn[k] = rsqrt(d2);
                 dist[k] = d2 * rn[k];
                 dmax = fmax(dmax, dist[k]);
-                emax = fmax(emax, fmax(fabs(dx[k]) * g.box.ib[0], fmax(fabs(dy[k]) * g.box.ib[1], fabs(dz[k]) * g.box.ib[2])));
             }
+            // no component of a neighbour vector reaches 0.49 box lengths if the longest vector stays below 0.49 of
+            // the shortest box edge (sufficient; tiny boxes may take the exact path a little more often)
+            emax = dmax * fmax(g.box.ib[0], fmax(g.box.ib[1], g.box.ib[2]));
             // every neighbour inside the smallest cell width is inside the guaranteed radius: the walls only matter beyond
             const double cwmin = fmin(g.cw[0], fmin(g.cw[1], g.cw[2]));
             const double rg = (dmax > cwmin - 1e-4) ? wol_guaranteed_radius(c, g, a.rows) : cwmin;
