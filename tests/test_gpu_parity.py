@@ -320,6 +320,33 @@ def test_both_proposal_kernels_agree_and_match_oracle(wp, oracle):
             assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_big_frames_in_small_batches(oracle):
+    """a few large frames: the streaming sort splits every frame over several blocks (count / scan / scatter) and the
+    long rows of a big box go through the four-slot row sort; fp64 and fp32 storage, sampled waters vs the oracle"""
+    import torch
+    from waterorderlib_amd import engine, synth
+    oracle.set_threads(8)
+    n, F = 420000, 3
+    xyz, boxes = synth.water_frames(n, 1, seed=301)
+    base = torch.from_numpy(xyz[0]).cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    frames = (base.unsqueeze(0) + 0.05 * torch.randn((F, n, 3), generator=g, device="cuda", dtype=torch.float64)).contiguous()
+    bx = np.tile(boxes[0][None, :], (F, 1))
+    res = engine.tet_order_traj(frames, bx, want_q=True)
+    res32 = engine.tet_order_traj(frames.to(torch.float32), bx, want_q=True)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    sample = rng.choice(n, 1500, replace=False)
+    for t in (0, F - 1):
+        pos = frames[t].cpu().numpy()
+        q_o = oracle.getOrderParamq(pos[sample], pos, boxes[0], cells=True)
+        np.testing.assert_allclose(res.q[t].cpu().numpy()[sample], q_o, rtol=0, atol=Q_TOL)
+        pos32 = frames[t].to(torch.float32).cpu().numpy().astype(np.float64)
+        q_o32 = oracle.getOrderParamq(pos32[sample], pos32, boxes[0], cells=True)
+        np.testing.assert_allclose(res32.q[t].cpu().numpy().astype(np.float64)[sample], q_o32, rtol=0, atol=2e-7)
+    assert int(res.qhist.sum().item()) <= F * n and int(res.dhist.sum().item()) == 4 * F * n
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_boxes_and_densities_vs_oracle(wp, oracle, seed):
     """seeded sweep over box shapes (3 to ~25 cells per axis), densities and clustering -- tiles that wrap around the

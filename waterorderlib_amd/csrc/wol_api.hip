@@ -447,32 +447,66 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         for (int f = 0; f < F; ++f) ncell_max = std::max(ncell_max, gh[f].ncell);
         const size_t sort_lds = sizeof(int) * ((size_t)ncell_max + 1);
         const bool lds_sort = F >= 128 && sort_lds + sizeof(int) * WOL_SORT_BLOCK + 1024 <= 160 * 1024 && c->lds_sort;
-        bool layer_sort = c->lds_sort && F >= 64;
+        // streaming two-level sort ((z, y) row buckets, then a counting sort inside every row): one block per frame
+        // when the batch has enough frames to fill the chip that way, else every frame split over P blocks
+        // (count / scan / scatter launches) -- big frames come in small batches
+        bool layer_sort = c->lds_sort && (F >= 64 || (int64_t)F * n >= 400000);
         int nz_max = 0, nrow_max = 0;
         for (int f = 0; f < F && layer_sort; ++f) {
             if (gh[f].maxshell < 0) { layer_sort = false; break; }
-            if (gh[f].nc[0] > WOL_L2_MAXNX || gh[f].nc[1] * gh[f].nc[2] > WOL_L1_MAXROWS) layer_sort = false;
+            if (gh[f].nc[0] > WOL_L2_MAXNX || gh[f].nc[1] * gh[f].nc[2] > WOL_L1_MAXROWS_BIG) layer_sort = false;
             nz_max = std::max(nz_max, gh[f].nc[2]);
             nrow_max = std::max(nrow_max, gh[f].nc[1] * gh[f].nc[2]);
         }
+        const bool big_rows = nrow_max > WOL_L1_MAXROWS;
+        int P = 1;
+        if (layer_sort && (F < 64 || big_rows)) {
+            P = std::min(64, std::max(1, (2 * c->num_cus + F - 1) / F));          // about two blocks per CU
+            P = std::min(P, std::max(1, n / (4 * WOL_SORT_BLOCK)));                  // at least a few chunks each
+            if (P == 1 && big_rows) P = 2;                                           // the fused kernel's tables end at MAXROWS
+        }
         if (layer_sort) {
-            // streaming two-level sort: (z, y) row buckets, then a counting sort inside every row
             const int ro_stride = nrow_max + 1;
             WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
             WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
-            const size_t l1_lds = wol_sort_rows_lds(nrow_max);
-            if (l1_lds > c->sort_rows_lds_set) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wol_sort_rows_lds(WOL_L1_MAXROWS)));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wol_sort_rows_lds(WOL_L1_MAXROWS)));
-                c->sort_rows_lds_set = wol_sort_rows_lds(WOL_L1_MAXROWS);
+            if (!c->sort_rows_lds_set) {
+                const int lds_a = (int)wol_sort_rows_lds(WOL_L1_MAXROWS, WOL_L1_CHUNK);
+                const int lds_b = (int)wol_sort_rows_lds(WOL_L1_MAXROWS_BIG, WOL_L1_CHUNK_BIG);
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+                c->sort_rows_lds_set = 1;
             }
-            hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), l1_lds, ss, fv,
-                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
-            hipLaunchKernelGGL(k_sort_in_row, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
-                               c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
-                               S.sorted.as<double4>(), s32);
+            if (P == 1) {
+                hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
+                                   S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
+            } else {
+                WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * P * ro_stride));   // per-block row counts, then cursors
+                int* cntb = c->rank.as<int>();
+                hipLaunchKernelGGL(k_sort_rows_count<T>, dim3(P, F), dim3(WOL_SORT_BLOCK), sizeof(int) * (size_t)(nrow_max + 1), ss, fv,
+                                   S.grids.as<FrameGrid>(), cntb, ro_stride, P);
+                hipLaunchKernelGGL(k_sort_rows_scan, dim3(F), dim3(WOL_SORT_BLOCK), 0, ss, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                                   c->layer_off.as<int>(), ro_stride);
+                if (big_rows)
+                    hipLaunchKernelGGL((k_sort_rows_scatter<T, WOL_L1_CHUNK_BIG>), dim3(P, F), dim3(WOL_SORT_BLOCK),
+                                       wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_BIG), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                                       c->sort_tmp.as<double4>(), nrow_max);
+                else
+                    hipLaunchKernelGGL((k_sort_rows_scatter<T, WOL_L1_CHUNK>), dim3(P, F), dim3(WOL_SORT_BLOCK),
+                                       wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                                       c->sort_tmp.as<double4>(), nrow_max);
+            }
+            if ((int64_t)n > 100 * (int64_t)nrow_max)   // long rows (big boxes): four waters per lane
+                hipLaunchKernelGGL(k_sort_in_row<4>, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<double4>(), s32);
+            else
+                hipLaunchKernelGGL(k_sort_in_row<2>, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<double4>(), s32);
         } else if (lds_sort) {
             if (sort_lds > c->sort_lds_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_frame_lds<T>),

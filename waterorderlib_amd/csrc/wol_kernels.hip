@@ -225,100 +225,57 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
 #define WOL_L1_MAXROWS 4080   // nz * ny rows counted in LDS by level 1 (three tables + the chunk staging within 160 KB)
 #define WOL_L2_MAXNX 128      // cells of a row handled by one wave of level 2
 #define WOL_L1_CHUNK 3            // waters per thread and chunk of level 1 (chunk = 3 * 1024 waters: 96 KB of staging)
-// dynamic LDS of k_sort_rows for a frame with nrow cell rows
-__host__ __device__ inline size_t wol_sort_rows_lds(int nrow) {
-    return (size_t)WOL_L1_CHUNK * WOL_SORT_BLOCK * (sizeof(double4) + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
+#define WOL_L1_CHUNK_BIG 2        // ... for frames with more rows than WOL_L1_MAXROWS (tables up to WOL_L1_MAXROWS_BIG rows)
+#define WOL_L1_MAXROWS_BIG 6800
+// dynamic LDS of the level-1 kernels for a frame with nrow cell rows and chunks of ch * 1024 waters
+__host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch) {
+    return (size_t)ch * WOL_SORT_BLOCK * (sizeof(double4) + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
 }
-template <typename T>
-__global__ void __launch_bounds__(WOL_SORT_BLOCK)
-k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
-            double4* __restrict__ tmp, int nrow_cap) {
-    // A lane's 32-byte store to its water's row bucket is a transaction of its own (64 per wave instruction): the
-    // scatter alone cost 0.23 ms of 0.61.  So a chunk of 3072 waters is first ordered by row inside LDS (returning
-    // atomic = rank inside the row, a scan over the rows) and then written out in that order: a row's ~3 waters of
-    // the chunk are consecutive lanes writing consecutive addresses.
-    extern __shared__ double4 lds_sort_rows[];
-    constexpr int C = WOL_L1_CHUNK * WOL_SORT_BLOCK;
-    double4* stage = lds_sort_rows;                                 // [C] the chunk in row order
-    int* dest = reinterpret_cast<int*>(stage + C);                   // [C] its slots in tmp[]
-    int* cnt = dest + C;                                             // [nrow + 1] row cursors in tmp[]
-    int* icnt = cnt + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
-    int* delta = icnt + (nrow_cap + 1);                              // [nrow + 1] cursor - start of the row in this chunk
-    __shared__ int part[WOL_SORT_BLOCK];
-    __shared__ int wtot[WOL_SORT_BLOCK / 64];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FrameGrid& g = grids[f];
+
+// The scatter of level 1 for waters [i_begin, i_end) of a frame, cnt[] holding the row cursors in tmp[]:
+// a lane's 32-byte store to its water's row bucket is a transaction of its own (64 per wave instruction) -- the
+// scatter alone cost 0.23 ms of 0.61.  So a chunk of CH * 1024 waters is first ordered by row inside LDS (returning
+// atomic = rank inside the row, a scan over the rows) and then written out in that order: a row's waters of the
+// chunk are consecutive lanes writing consecutive addresses.  The next chunk's coordinates are fetched while the
+// current one goes through LDS.  icnt[] must be zero on entry (and is on exit).
+template <typename T, int CH>
+__device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base, int64_t atom_stride, int i_begin, int i_end,
+                                                     const FrameGrid& g, int* cnt, int* icnt, int* delta, double4* stage,
+                                                     int* dest, int* wtot, double4* __restrict__ out) {
+    constexpr int C = CH * WOL_SORT_BLOCK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
-    const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
-    for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) { cnt[c] = 0; icnt[c] = 0; }
-    __syncthreads();
-#ifndef WOL_SORT_U
-#define WOL_SORT_U 8
-#endif
-    constexpr int U = WOL_SORT_U;
-    for (int i0 = tid; i0 < fv.n; i0 += WOL_SORT_BLOCK * U) {
-        double y[U], z[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * WOL_SORT_BLOCK;
-            if (i < fv.n) { const T* p = base + (int64_t)i * fv.atom_stride; y[u] = (double)p[1]; z[u] = (double)p[2]; }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (i0 + u * WOL_SORT_BLOCK < fv.n)
-                atomicAdd(&cnt[wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr)], 1);
-    }
-    __syncthreads();
-    // exclusive scan of the row counters in place
     const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
     const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
-    int s = 0;
-    for (int k = sb; k < se; ++k) s += cnt[k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
-        const int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int* ro = row_off + (int64_t)f * ro_stride;
-    int run = part[tid] - s;
-    for (int k = sb; k < se; ++k) { const int v = cnt[k]; cnt[k] = run; ro[k] = run; run += v; }
-    if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
-    __syncthreads();
-    double4* __restrict__ out = tmp + (int64_t)f * fv.n;
-    // the next chunk's coordinates are fetched while the current one goes through LDS (one block per CU: nothing
-    // else would cover the load latency)
-    double nx_[WOL_L1_CHUNK], ny_[WOL_L1_CHUNK], nz_[WOL_L1_CHUNK];
+    double nx_[CH], ny_[CH], nz_[CH];
 #pragma unroll
-    for (int u = 0; u < WOL_L1_CHUNK; ++u) {
-        const int i = u * WOL_SORT_BLOCK + tid;
-        if (i < fv.n) {
-            const T* p = base + (int64_t)i * fv.atom_stride;
+    for (int u = 0; u < CH; ++u) {
+        const int i = i_begin + u * WOL_SORT_BLOCK + tid;
+        if (i < i_end) {
+            const T* p = base + (int64_t)i * atom_stride;
             nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
         }
     }
-    for (int c0 = 0; c0 < fv.n; c0 += C) {
-        const int cn = min(C, fv.n - c0);
+    for (int c0 = i_begin; c0 < i_end; c0 += C) {
+        const int cn = min(C, i_end - c0);
         // (1) the chunk's waters: row and rank inside the row
-        double x[WOL_L1_CHUNK], y[WOL_L1_CHUNK], z[WOL_L1_CHUNK];
-        int row[WOL_L1_CHUNK], lr[WOL_L1_CHUNK];
+        double x[CH], y[CH], z[CH];
+        int row[CH], lr[CH];
 #pragma unroll
-        for (int u = 0; u < WOL_L1_CHUNK; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
+        for (int u = 0; u < CH; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
 #pragma unroll
-        for (int u = 0; u < WOL_L1_CHUNK; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int i = c0 + C + u * WOL_SORT_BLOCK + tid;
-            if (i < fv.n) {
-                const T* p = base + (int64_t)i * fv.atom_stride;
+            if (i < i_end) {
+                const T* p = base + (int64_t)i * atom_stride;
                 nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
             }
         }
 #pragma unroll
-        for (int u = 0; u < WOL_L1_CHUNK; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int i = c0 + u * WOL_SORT_BLOCK + tid;
             row[u] = -1;
-            if (i < fv.n) {
+            if (i < i_end) {
                 row[u] = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
                 lr[u] = atomicAdd(&icnt[row[u]], 1);
             }
@@ -348,7 +305,7 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
         __syncthreads();
         // (3) into the staging area in row order
 #pragma unroll
-        for (int u = 0; u < WOL_L1_CHUNK; ++u)
+        for (int u = 0; u < CH; ++u)
             if (row[u] >= 0) {
                 const int k = icnt[row[u]] + lr[u];
                 double4 v;
@@ -365,12 +322,156 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     }
 }
 
-#define WOL_L2_CAP 128        // waters of a row sorted through registers and LDS (two per lane); longer rows: direct form
+// histogram of the (z, y) cell rows of waters [i_begin, i_end) into cnt[] (LDS, zeroed by the caller)
+template <typename T>
+__device__ __forceinline__ void wol_sort_rows_count(const T* __restrict__ base, int64_t atom_stride, int i_begin, int i_end,
+                                                    const FrameGrid& g, int* cnt) {
+#ifndef WOL_SORT_U
+#define WOL_SORT_U 8
+#endif
+    constexpr int U = WOL_SORT_U;
+    const int tid = threadIdx.x, ny = g.nc[1], nz = g.nc[2];
+    for (int i0 = i_begin + tid; i0 < i_end; i0 += WOL_SORT_BLOCK * U) {
+        double y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * WOL_SORT_BLOCK;
+            if (i < i_end) { const T* p = base + (int64_t)i * atom_stride; y[u] = (double)p[1]; z[u] = (double)p[2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * WOL_SORT_BLOCK < i_end)
+                atomicAdd(&cnt[wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr)], 1);
+    }
+}
+
+// one block per frame: count, scan, scatter (the batch has enough frames to fill the chip)
+template <typename T>
+__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
+            double4* __restrict__ tmp, int nrow_cap) {
+    extern __shared__ double4 lds_sort_rows[];
+    constexpr int C = WOL_L1_CHUNK * WOL_SORT_BLOCK;
+    double4* stage = lds_sort_rows;                                 // [C] the chunk in row order
+    int* dest = reinterpret_cast<int*>(stage + C);                   // [C] its slots in tmp[]
+    int* cnt = dest + C;                                             // [nrow + 1] row cursors in tmp[]
+    int* icnt = cnt + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
+    int* delta = icnt + (nrow_cap + 1);                              // [nrow + 1] cursor - start of the row in this chunk
+    __shared__ int part[WOL_SORT_BLOCK];
+    __shared__ int wtot[WOL_SORT_BLOCK / 64];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameGrid& g = grids[f];
+    const int nrow = g.nc[1] * g.nc[2];
+    const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
+    for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) { cnt[c] = 0; icnt[c] = 0; }
+    __syncthreads();
+    wol_sort_rows_count<T>(base, fv.atom_stride, 0, fv.n, g, cnt);
+    __syncthreads();
+    // exclusive scan of the row counters in place
+    const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
+    const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
+    int s = 0;
+    for (int k = sb; k < se; ++k) s += cnt[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int* ro = row_off + (int64_t)f * ro_stride;
+    int run = part[tid] - s;
+    for (int k = sb; k < se; ++k) { const int v = cnt[k]; cnt[k] = run; ro[k] = run; run += v; }
+    if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
+    __syncthreads();
+    wol_sort_rows_chunks<T, WOL_L1_CHUNK>(base, fv.atom_stride, 0, fv.n, g, cnt, icnt, delta, stage, dest, wtot,
+                                          tmp + (int64_t)f * fv.n);
+}
+
+// ---- the same with every frame split over P blocks (big frames in small batches): three launches ----
+// (a) block (p, f): rows histogram of its share of the frame -> cntb[f][p][row]
+template <typename T>
+__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+k_sort_rows_count(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ cntb, int stride, int P) {
+    extern __shared__ int lds_rows_count[];
+    const int p = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const FrameGrid& g = grids[f];
+    const int nrow = g.nc[1] * g.nc[2];
+    for (int c = tid; c < nrow; c += WOL_SORT_BLOCK) lds_rows_count[c] = 0;
+    __syncthreads();
+    const int per = (fv.n + P - 1) / P;
+    wol_sort_rows_count<T>(fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, min(p * per, fv.n), min((p + 1) * per, fv.n), g,
+                           lds_rows_count);
+    __syncthreads();
+    int* o = cntb + ((int64_t)f * P + p) * stride;
+    for (int c = tid; c < nrow; c += WOL_SORT_BLOCK) o[c] = lds_rows_count[c];
+}
+
+// (b) block f: row offsets of the frame and, in place of the counts, every block's first slot in every row
+__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+k_sort_rows_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cntb, int stride, int P, int* __restrict__ row_off,
+                 int ro_stride) {
+    __shared__ int part[WOL_SORT_BLOCK];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameGrid& g = grids[f];
+    const int nrow = g.nc[1] * g.nc[2];
+    const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
+    const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
+    int* cb = cntb + (int64_t)f * P * stride;
+    int s = 0;
+    for (int k = sb; k < se; ++k)
+        for (int p = 0; p < P; ++p) s += cb[(int64_t)p * stride + k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int* ro = row_off + (int64_t)f * ro_stride;
+    int run = part[tid] - s;
+    for (int k = sb; k < se; ++k) {
+        ro[k] = run;
+        for (int p = 0; p < P; ++p) { const int v = cb[(int64_t)p * stride + k]; cb[(int64_t)p * stride + k] = run; run += v; }
+    }
+    if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
+}
+
+// (c) block (p, f): its share of the frame into the row buckets, from its cursors
+template <typename T, int CH>
+__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+k_sort_rows_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __restrict__ cntb, int stride, int P,
+                    double4* __restrict__ tmp, int nrow_cap) {
+    extern __shared__ double4 lds_sort_rows[];
+    constexpr int C = CH * WOL_SORT_BLOCK;
+    double4* stage = lds_sort_rows;
+    int* dest = reinterpret_cast<int*>(stage + C);
+    int* cnt = dest + C;
+    int* icnt = cnt + (nrow_cap + 1);
+    int* delta = icnt + (nrow_cap + 1);
+    __shared__ int wtot[WOL_SORT_BLOCK / 64];
+    const int p = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+    const FrameGrid& g = grids[f];
+    const int nrow = g.nc[1] * g.nc[2];
+    const int* cur = cntb + ((int64_t)f * P + p) * stride;
+    for (int c = tid; c < nrow; c += WOL_SORT_BLOCK) { cnt[c] = cur[c]; icnt[c] = 0; }
+    __syncthreads();
+    const int per = (fv.n + P - 1) / P;
+    wol_sort_rows_chunks<T, CH>(fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, min(p * per, fv.n), min((p + 1) * per, fv.n),
+                                g, cnt, icnt, delta, stage, dest, wtot, tmp + (int64_t)f * fv.n);
+}
+
+// SLOTS waters per lane of a row are sorted through registers and LDS (rows of up to 64 * SLOTS waters; longer
+// rows take the direct form): 2 for the usual ~100-water rows, 4 for the long rows of big boxes
+template <int SLOTS>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
               const double4* __restrict__ tmp, int n, int* __restrict__ cell_start,
               double4* __restrict__ sorted, float4* __restrict__ sorted32) {
     __shared__ int cnt_all[(WOL_BLOCK / 64) * WOL_L2_MAXNX];
+    constexpr int WOL_L2_CAP = 64 * SLOTS;
     __shared__ double4 st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];   // the row in cell order, written out linearly:
     __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
     const int f = blockIdx.y, cz = blockIdx.x;
@@ -394,11 +495,11 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         __builtin_amdgcn_wave_barrier();
         if (e - b <= WOL_L2_CAP) {
             // ---- the usual row: read once (two waters per lane stay in registers), rank = returning LDS atomic ----
-            double4 v[2];
-            float4 w[2];
-            int cxs[2], rank[2];
+            double4 v[SLOTS];
+            float4 w[SLOTS];
+            int cxs[SLOTS], rank[SLOTS];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < SLOTS; ++u) {
                 const int i = b + lane + 64 * u;
                 cxs[u] = -1;
                 if (i < e) {
@@ -431,7 +532,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < SLOTS; ++u)
                 if (cxs[u] >= 0) {
                     const int d = cnt[cxs[u]] + rank[u];
                     st64[d] = v[u];
