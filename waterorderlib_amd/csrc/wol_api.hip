@@ -105,6 +105,7 @@ struct wol_ctx {
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
     size_t sort_rows_lds_set = 0;
+    int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
@@ -465,6 +466,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             P = std::min(P, std::max(1, n / (4 * WOL_SORT_BLOCK)));                  // at least a few chunks each
             if (P == 1 && big_rows) P = 2;                                           // the fused kernel's tables end at MAXROWS
         }
+        if (layer_sort && c->sort_parts > 0) P = c->sort_parts;                      // tuning override
         if (layer_sort) {
             const int ro_stride = nrow_max + 1;
             WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
@@ -879,6 +881,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->inputs_resident = value != 0.0;
     } else if (k == "search_rows") {
         c->search_rows = value != 0.0;
+    } else if (k == "sort_parts") {
+        c->sort_parts = (int)value;
     } else if (k == "search_margin") {
         c->search_margin = (int)value;
     } else if (k == "overlap") {
