@@ -1,22 +1,23 @@
-// wol_search_fast.hip -- the filtered neighbour-search kernel (included by wol_api.hip).
+// wol_search_fast.hip -- the filtered neighbour search (included by wol_api.hip): the shared pieces (FastArgs, the
+// branch-free top-5 insert), the 3-D tile proposal kernel k_search_fast, the certification kernel k_finish_fast and
+// the exact kernel for the waters the filter cannot certify, k_search_exact_list.  The default proposal kernel is
+// k_search_rows (wol_search_rows.hip); k_search_fast is the fallback for frames of more than 2^20 waters and the
+// second opinion in the tests.
 //
-// One 256-thread workgroup owns a TILE of the cell grid (sx cells along x by ry rows along y in one
-// z layer, ~220 waters) and stages the tile plus its one-cell halo -- 3*(ry+2) rows of sx+2 cells,
-// periodic images already shifted into the tile's local frame -- from the cell-sorted fp64 array
-// into LDS as fp32 coordinates (x, y, z pre-scaled so that a squared distance comes out in integer
-// key units, w = slot in the sorted array).  Each lane owns one water of the tile and sweeps the
-// 27 cells around it: nine contiguous LDS spans, 13 VALU ops per candidate:
-//     3 v_sub, 3 v_fma (the first adds 2^23, which turns the float into a fixed-point integer),
-//     v_min (saturate), v_lshl_or (key = d2 << 11 | LDS index), and a branch-free sorted top-5
-//     insert made of one v_min_u32 + four v_med3_u32 that are independent of each other.
-// The fp32 keys only PROPOSE the four nearest neighbours.  They are accepted when the proposal is
-// provably the exact answer -- the 5th key is more than 2*eps above the 4th (eps = bound on the
-// fp32 error in key units) and, after re-evaluating the four finalists from the fp64 coordinates
-// with the reference's exact arithmetic (wol_eval_pair), the 4th distance lies inside the radius
-// that the 27-cell stencil guarantees to be complete.  Everything else (near-ties, sparse
-// neighbourhoods, dense cells that overflow the tile buffer) is appended to a list that
-// k_search_exact_list finishes with the exact shell-walking search.  So the results are those of
-// the exact path by construction; the filter only decides who needs it.
+// k_search_fast: a 512-thread workgroup owns a 3-D TILE of the cell grid (sx x ry x sz cells, ~480 waters = one lane
+// each) and stages the tile plus its one-cell halo -- periodic images already shifted into the tile's local frame --
+// from the cell-sorted fp32 array into LDS as pair records (x0,x1,y0,y1)(z0,z1,id0,id1), pre-scaled so that a squared
+// distance comes out in integer key units.  Each lane sweeps the 27 cells around its water as nine contiguous LDS
+// spans, per candidate pair: 3 v_pk_add_f32, 3 v_pk_fma_f32 (the first adds 2^23, which turns the float into a
+// fixed-point integer), 2 x (v_min saturate, v_lshl_or key = d2 << 12 | LDS index) and two branch-free sorted top-5
+// inserts (one v_min_u32 + four v_med3_u32 each).
+// The fp32 keys only PROPOSE the four nearest neighbours.  They are accepted when the proposal is provably the exact
+// answer -- the 5th key is more than 2*eps above the 4th (eps = bound on the fp32 error in key units) and, after
+// re-evaluating the four finalists from the fp64 coordinates with the reference's arithmetic (k_finish_fast), the 4th
+// distance lies inside the radius the proposal kernel's stencil guarantees to be complete.  Everything else
+// (near-ties, sparse neighbourhoods, dense cells that overflow the tile buffer) is appended to a list that
+// k_search_exact_list finishes with the exact shell-walking search.  So the results are those of the exact path by
+// construction; the filter only decides who needs it.
 #pragma once
 
 // Geometry of the proposal kernel (overridable at build time for tuning runs).
