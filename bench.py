@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--cpu-sample-waters", type=int, default=10000)
     ap.add_argument("--search-rows", type=int, default=-1, help="proposal kernel: 1 row-merged tiles, 0 3-D tiles (default: library default)")
     ap.add_argument("--overlap", type=int, default=-1, help="1: sort of the next batch on a second stream beside search/finish")
+    ap.add_argument("--frames-per-batch", type=int, default=-1, help="library batch size (0 = automatic)")
     ap.add_argument("--sort-parts", type=int, default=-1, help="blocks per frame of the sort's first level (0 = automatic)")
     ap.add_argument("--search-margin", type=int, default=-1, help="blocks per CU the proposal kernel leaves free")
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -129,6 +130,8 @@ def main():
     if args.overlap >= 0:
         ctx.set_option("overlap", args.overlap)
         ctx.set_option("inputs_resident", 1)
+    if args.frames_per_batch >= 0:
+        ctx.set_option("frames_per_batch", args.frames_per_batch)
     if args.sort_parts >= 0:
         ctx.set_option("sort_parts", args.sort_parts)
     if args.search_margin >= 0:

@@ -257,7 +257,7 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
         // ---- tiles of the row-merged kernel (wol_search_rows.hip): sx cells x ry rows in one z layer;
         //      staged = (ry + 2) triples of three z rows, sx + 2 cells long ----
         g->row_tiles_max = 0;
-        int rmax_sx = 1;
+        int rmax_sx = 1, rmax_ry = 1;
         for (int l = 0; l < WOL_NLEV; ++l) {
             const double w = wpc * lev_mult[l] / 1.10;
             double best = -1.0;
@@ -285,6 +285,7 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
             g->row_ntiles[l] = bntx * bnty * g->nc[2];
             g->row_tiles_max = std::max(g->row_tiles_max, g->row_ntiles[l]);
             rmax_sx = std::max(rmax_sx, bsx);
+            rmax_ry = std::max(rmax_ry, bry);
         }
         {
             // per-axis coordinate magnitudes: x up to half the staged tile length, y half the staged rows
@@ -294,10 +295,14 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
                 return std::ldexp(1.0, (int)std::ceil(std::log2(Mk)) - 24);
             };
             const double ux = ulp_of(0.5 * (rmax_sx + 2) * g->cw[0] + g->cw[0]);
-            const double uy = ulp_of(0.5 * (WOL_ROWS_MAXRY + 2) * g->cw[1] + g->cw[1]);
+            const double uy = ulp_of(0.5 * (rmax_ry + 2) * g->cw[1] + g->cw[1]);
             const double uz = ulp_of(2.0 * g->cw[2]);
-            const double eps = 2.0 * (rmax * g->scale) * 2.0 * std::sqrt(ux * ux + uy * uy + uz * uz) + 1.5;
-            g->row_eps_units = (int)std::ceil(eps * 1.25) + 2;
+            // |key - exact d2| <= 2 d (2 |ulp|) + 1.5 in key units (d in sqrt(key units)), padded by 25 % + 2: a slope and
+            // an offset for the kernel's near-tie test at the distance in question, the value at rmax for everything else
+            const double slope = 2.0 * 2.0 * std::sqrt(ux * ux + uy * uy + uz * uz);
+            g->row_eps_a = (float)(1.25 * slope);
+            g->row_eps_b = (float)(1.25 * 1.5 + 2.0);
+            g->row_eps_units = (int)std::ceil((slope * (rmax * g->scale) + 1.5) * 1.25) + 2;
         }
     }
     return true;

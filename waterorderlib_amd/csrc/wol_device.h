@@ -41,6 +41,7 @@ struct FrameGrid {
     int row_ntiles[WOL_NLEV];
     int row_tiles_max;
     int row_eps_units;  // its bound on |fp32 key - exact d^2 * S| (longer tiles: larger coordinates)
+    float row_eps_a, row_eps_b;  // the same bound at distance d: a * sqrt(d^2 in key units) + b
     float scale;        // sqrt(S): staged coordinates are multiplied by it so d^2 comes out in key units
     float tmax;         // 2^23 + 2^21 - 1: saturation of the biased squared distance
     double S;           // key units per A^2 (2^21 / r2max)

@@ -357,7 +357,10 @@ k_search_rows(FastArgs a) {
                 }
                 const unsigned d3 = k3 >> WOL_ID_BITS, d4 = k4 >> WOL_ID_BITS;
                 const unsigned sat = (1u << (32 - WOL_ID_BITS)) - 1u - (unsigned)g.row_eps_units;
-                if (k3 != 0xFFFFFFFFu && d3 < sat && d4 - d3 > 2u * (unsigned)g.row_eps_units) {
+                // the proposal stands when the 5th key is separated from the 4th by more than both keys' fp32 error
+                // (bound evaluated at the 5th distance, the larger of the two)
+                const float eps4 = g.row_eps_a * __builtin_sqrtf((float)d4) + g.row_eps_b;
+                if (k3 != 0xFFFFFFFFu && d3 < sat && (float)(d4 - d3) > 2.0f * eps4) {
                     const unsigned m = (1u << WOL_ID_BITS) - 1u, sm = (1u << WOL_SLOT_BITS) - 1u;
                     auto slot_of = [&](unsigned key) -> int {
                         const unsigned e = key & m;
