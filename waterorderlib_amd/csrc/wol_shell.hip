@@ -313,6 +313,7 @@ k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long l
     extern __shared__ int lds_hist[];
     wol_hist_zero(lds_hist, totbins);
     __syncthreads();
+    const float inv_wf = (float)(1.0 / binwidth);
     for (int q = blockIdx.x * WOL_BLOCK + threadIdx.x; q < a.ns; q += gridDim.x * WOL_BLOCK) {
         double c[3];
         int row;
@@ -320,8 +321,13 @@ k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long l
         wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
             if (same && slot <= q) return;
             if (!(d2 > 0.0)) return;
-            const int bin = wol_dist_bin(sqrt(d2), binwidth, totbins);
-            if (bin >= 0) atomicAdd(&lds_hist[bin], 1);
+            // nbin = ceiling(sqrt(d2) / binwidth): guessed in fp32 and accepted when d2 lies strictly inside the squared
+            // edges of that bin with a 1e-12 margin (which covers the roundings of the reference's sqrt and division, so
+            // its ceiling is this bin); on or near an edge the reference's own expression decides
+            int k = (int)ceilf(__builtin_sqrtf((float)d2) * inv_wf);
+            const double lo = (double)(k - 1) * binwidth, hi = (double)k * binwidth;
+            if (!(d2 > lo * lo * (1.0 + 1e-12) && d2 < hi * hi * (1.0 - 1e-12))) k = (int)ceil(sqrt(d2) / binwidth);
+            if (k >= 1 && k <= totbins) atomicAdd(&lds_hist[k - 1], 1);
         });
     }
     __syncthreads();
