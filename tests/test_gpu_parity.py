@@ -320,6 +320,52 @@ def test_both_proposal_kernels_agree_and_match_oracle(wp, oracle):
             assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_npt_like_batch_with_changing_cell_counts(oracle):
+    """a constant-pressure trajectory: the box breathes, and across 13.5 A x k the number of cells per axis changes
+    from frame to frame inside one batch (different row tables, tile shapes and bin counts per frame)"""
+    import torch
+    from waterorderlib_amd import engine, synth
+    oracle.set_threads(8)
+    n, T = 6000, 96
+    xyz, boxes0 = synth.water_frames(n, 1, seed=401)
+    L0 = boxes0[0]                                      # ~56.4 A: 12 cells of 4.70; 54.0 / 58.5 are the thresholds
+    rng = np.random.default_rng(402)
+    scale = np.where(np.arange(T) % 3 == 0, 0.955, np.where(np.arange(T) % 3 == 1, 1.0, 1.04))[:, None] * (1.0 + 0.003 * rng.standard_normal((T, 3)))
+    boxes = L0[None, :] * scale
+    frames = (xyz[0][None, :, :] / L0) * boxes[:, None, :] + 0.05 * rng.standard_normal((T, n, 3))
+    assert len({tuple(np.floor(b / 4.5).astype(int)) for b in boxes}) >= 3
+    res = engine.tet_order_traj(torch.from_numpy(frames).cuda(), boxes, want_q=True)
+    qh = np.zeros(500, dtype=np.int64)
+    for t in range(T):
+        if t in (0, 1, 2, 50, T - 1):
+            q_o = oracle.getOrderParamq(frames[t], frames[t], boxes[t], cells=True)
+            np.testing.assert_allclose(res.q[t].cpu().numpy(), q_o, rtol=0, atol=Q_TOL)
+            assert abs(float(res.mean[t]) - np.mean(q_o)) < 1e-13
+    h = np.histogram(res.q.cpu().numpy().ravel(), bins=500, range=[0.0, 1.0])[0]
+    assert np.array_equal(res.qhist.cpu().numpy(), h)
+    assert int(res.dhist.sum().item()) == 4 * n * T
+
+
+def test_batch_mixing_periodic_and_open_frames(oracle):
+    """frames with a non-periodic axis (BoxL < 0: all-pairs kernels) inside a batch of periodic ones"""
+    import torch
+    from waterorderlib_amd import engine, synth
+    oracle.set_threads(8)
+    n, T = 1500, 70
+    xyz, boxes = synth.water_frames(n, T, seed=411)
+    boxes = boxes.copy()
+    open_frames = [3, 4, 40, 69]
+    for t in open_frames:
+        boxes[t, t % 3] = -1.0
+    res = engine.tet_order_traj(torch.from_numpy(xyz).cuda(), boxes, want_q=True)
+    for t in open_frames + [0, 5, 41]:
+        q_o = oracle.getOrderParamq(xyz[t], xyz[t], boxes[t], cells=bool(np.all(boxes[t] > 0)))
+        np.testing.assert_allclose(res.q[t].cpu().numpy(), q_o, rtol=0, atol=Q_TOL)
+        assert abs(float(res.mean[t]) - np.mean(q_o)) < 1e-13 and abs(float(res.var[t]) - np.var(q_o)) < 1e-13
+    h = np.histogram(res.q.cpu().numpy().ravel(), bins=500, range=[0.0, 1.0])[0]
+    assert np.array_equal(res.qhist.cpu().numpy(), h)
+
+
 def test_big_frames_in_small_batches(oracle):
     """a few large frames: the streaming sort splits every frame over several blocks (count / scan / scatter) and the
     long rows of a big box go through the four-slot row sort; fp64 and fp32 storage, sampled waters vs the oracle"""
