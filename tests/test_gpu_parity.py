@@ -366,6 +366,27 @@ def test_batch_mixing_periodic_and_open_frames(oracle):
     assert np.array_equal(res.qhist.cpu().numpy(), h)
 
 
+def test_nan_coordinates_do_not_fault(wp, oracle):
+    """a water with NaN coordinates (a corrupt frame) gets q = 0 as in the reference (all its comparisons are false);
+    nobody can have it as a neighbour; the other waters are unaffected and nothing faults -- single frame and trajectory"""
+    import torch
+    from waterorderlib_amd import engine, synth
+    xyz, boxes = synth.water_frames(2500, 70, seed=421)
+    pos, box = xyz[0].copy(), boxes[0]
+    pos[17] = np.nan
+    pos[1200, 1] = np.inf
+    q = wp.getOrderParamq(pos, pos, box)
+    q_o = oracle.getOrderParamq(pos, pos, box)            # literal O(N^2) form: NaN distances fail every test
+    assert q[17] == 0.0 and q[1200] == 0.0
+    np.testing.assert_allclose(q, q_o, rtol=0, atol=Q_TOL)
+    xyz[5, 17] = np.nan
+    xyz[60, 99, 2] = -np.inf
+    res = engine.tet_order_traj(torch.from_numpy(xyz).cuda(), boxes, want_q=True)
+    qt = res.q.cpu().numpy()
+    assert qt[5, 17] == 0.0 and qt[60, 99] == 0.0 and np.all(np.isfinite(qt))
+    np.testing.assert_allclose(qt[5], oracle.getOrderParamq(xyz[5], xyz[5], boxes[5]), rtol=0, atol=Q_TOL)
+
+
 def test_big_frames_in_small_batches(oracle):
     """a few large frames: the streaming sort splits every frame over several blocks (count / scan / scatter) and the
     long rows of a big box go through the four-slot row sort; fp64 and fp32 storage, sampled waters vs the oracle"""
