@@ -637,7 +637,9 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
     if (c->sort_stream) HIP_TRY(hipStreamSynchronize(c->sort_stream));  // rare path: keep it simple
     WOL_TRY(c->grids_host.ensure(sizeof(FrameGrid)));
     FrameGrid* gh = c->grids_host.as<FrameGrid>();
-    const bool ok = make_grid(box, n, std::fmax(reach * 0.5, 2.5), reach, gh);
+    // cells as wide as the reach (27-cell walk) for short reaches, half the reach (125 cells) for long ones: the
+    // smaller candidate volume of the two that keeps cells above 2.5 A (empty cells still cost a table entry)
+    const bool ok = make_grid(box, n, reach < 5.0 ? reach * 1.001 : std::fmax(reach * 0.5, 2.5), reach, gh);
     if (!ok) { gh->ncell = 1; for (int k = 0; k < 3; ++k) gh->nc[k] = 1; }
     gh->cell_base = 0;
     const size_t pe = 3 * (size_t)n, se = sub ? 3 * (size_t)ns : 0;

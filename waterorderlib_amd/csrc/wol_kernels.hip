@@ -45,30 +45,41 @@ k_bin_count(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     rank[(int64_t)f * fv.n + i] = r;
 }
 
-// exclusive scan of cell_count[0..ncell) in place; cell_count[ncell] receives the total
+// exclusive scan of cell_count[0..ncell) in place; cell_count[ncell] receives the total.  One block per frame goes
+// through the table in tiles of 4096 (four consecutive entries per thread: the block's accesses are one contiguous
+// stream), wave scans by shuffle, a running carry between tiles.
 __global__ void __launch_bounds__(1024)
 k_cell_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count) {
+    __shared__ int wsum[16];
     const FrameGrid& g = grids[blockIdx.x];
     int* c = cell_count + g.cell_base;
     const int ncell = g.ncell;
-    const int tid = threadIdx.x;
-    const int per = (ncell + 1023) / 1024;
-    const int b = min(tid * per, ncell);
-    const int e = min(b + per, ncell);
-    int s = 0;
-    for (int k = b; k < e; ++k) s += c[k];
-    __shared__ int part[1024];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan of the partials
-        int v = (tid >= off) ? part[tid - off] : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int carry = 0;
+    for (int t0 = 0; t0 < ncell; t0 += 4096) {
+        const int i = t0 + 4 * tid;
+        int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i + u < ncell) ? c[i + u] : 0;
+        const int s = (v[0] + v[1]) + (v[2] + v[3]);
+        int inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int x = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += x;
+        }
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        part[tid] += v;
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const int x = wsum[w]; total += x; if (w < wave) before += x; }
+        int run = carry + before + inc - s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { if (i + u < ncell) c[i + u] = run; run += v[u]; }
+        carry += total;
         __syncthreads();
     }
-    int run = part[tid] - s;
-    for (int k = b; k < e; ++k) { int v = c[k]; c[k] = run; run += v; }
-    if (tid == 1023) c[ncell] = part[1023];
+    if (tid == 0) c[ncell] = carry;
 }
 
 template <typename T>

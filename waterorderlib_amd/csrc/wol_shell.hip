@@ -85,31 +85,40 @@ k_shell_count(ShellArgs a, int* __restrict__ count) {
     count[row] = k;
 }
 
-// exclusive scans of k and of k(k-1)/2 over the rows (one block; ns is at most a few 1e5)
+// exclusive scans of k and of k(k-1)/2 over the rows: one block, tiles of 4096 rows (four consecutive per thread),
+// wave scans by shuffle, running carries
 __global__ void __launch_bounds__(1024)
 k_shell_offsets(const int* __restrict__ count, int ns, long long* __restrict__ off_nbr,
                 long long* __restrict__ off_ang, long long* __restrict__ totals) {
-    __shared__ long long pa[1024], pb[1024];
-    const int tid = threadIdx.x;
-    const int per = (ns + 1023) / 1024;
-    const int b = min(tid * per, ns), e = min(b + per, ns);
-    long long sa = 0, sb = 0;
-    for (int i = b; i < e; ++i) { const long long k = count[i]; sa += k; sb += k * (k - 1) / 2; }
-    pa[tid] = sa; pb[tid] = sb;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const long long va = tid >= off ? pa[tid - off] : 0, vb = tid >= off ? pb[tid - off] : 0;
+    __shared__ long long wa[16], wb[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long ca = 0, cb = 0;
+    for (int t0 = 0; t0 < ns; t0 += 4096) {
+        const int i = t0 + 4 * tid;
+        long long k[4], sa = 0, sb = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { k[u] = (i + u < ns) ? count[i + u] : 0; sa += k[u]; sb += k[u] * (k[u] - 1) / 2; }
+        long long ia = sa, ib = sb;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long xa = __shfl_up(ia, off, 64), xb = __shfl_up(ib, off, 64);
+            if (lane >= off) { ia += xa; ib += xb; }
+        }
+        if (lane == 63) { wa[wave] = ia; wb[wave] = ib; }
         __syncthreads();
-        pa[tid] += va; pb[tid] += vb;
+        long long ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { ta += wa[w]; tb += wb[w]; if (w < wave) { ba += wa[w]; bb += wb[w]; } }
+        long long ra = ca + ba + ia - sa, rb = cb + bb + ib - sb;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u < ns) { off_nbr[i + u] = ra; off_ang[i + u] = rb; }
+            ra += k[u]; rb += k[u] * (k[u] - 1) / 2;
+        }
+        ca += ta; cb += tb;
         __syncthreads();
     }
-    long long ra = pa[tid] - sa, rb = pb[tid] - sb;
-    for (int i = b; i < e; ++i) {
-        const long long k = count[i];
-        off_nbr[i] = ra; off_ang[i] = rb;
-        ra += k; rb += k * (k - 1) / 2;
-    }
-    if (tid == 1023) { totals[0] = pa[1023]; totals[1] = pb[1023]; }
+    if (tid == 0) { totals[0] = ca; totals[1] = cb; }
 }
 
 // ---- getCosAngs pass 2: list the shell (ascending original index), all pair angles ----------
