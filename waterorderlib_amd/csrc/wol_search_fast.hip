@@ -577,27 +577,40 @@ k_finish_fast(FastArgs a) {
             // The minimum-image vectors d themselves stand in for the reference's (apos + d) - apos (wp:372-373) and
             // for tetraCosAng's second re-image: they differ by rounding of order ulp(apos), 1e-15 relative, which q
             // tolerates (|dq| < 1e-14) and the distance bins do not notice except on a bin edge -- there the
-            // reference's chain is evaluated (below).  One rsqrt per neighbour gives both its norm and its distance.
-            double dx[4], dy[4], dz[4], rn[4], dist[4];
-            double dmax = 0.0, emax = 0.0;
+            // reference's chain is evaluated.  One rsqrt per neighbour gives both its norm and its distance.
+            // Per neighbour only its unit vector and its distance bin stay live (register pressure decides how many
+            // waves cover the gathers' latency).
+            double ux[4], uy[4], uz[4];
+            int dbin[4];
+            double dmax = 0.0;
             bool all_in = true;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // waterlib.f90:733-735 with rint for anint: they differ only on exact half-integers, i.e. a neighbour
                 // at exactly half a box length, which the emax test below sends to the exact path anyway
                 const double ex = nb[k].x - c[0], ey = nb[k].y - c[1], ez = nb[k].z - c[2];
-                dx[k] = ex - g.box.L[0] * rint(ex * g.box.ib[0]);
-                dy[k] = ey - g.box.L[1] * rint(ey * g.box.ib[1]);
-                dz[k] = ez - g.box.L[2] * rint(ez * g.box.ib[2]);
-                const double d2 = wol_sumsq(dx[k], dy[k], dz[k]);
+                const double dx = ex - g.box.L[0] * rint(ex * g.box.ib[0]);
+                const double dy = ey - g.box.L[1] * rint(ey * g.box.ib[1]);
+                const double dz = ez - g.box.L[2] * rint(ez * g.box.ib[2]);
+                const double d2 = wol_sumsq(dx, dy, dz);
                 all_in = all_in && (d2 > 0.0) && (d2 <= a.highsq);
-                rn[k] = rsqrt(d2);
-                dist[k] = d2 * rn[k];
-                dmax = fmax(dmax, dist[k]);
+                const double rn = rsqrt(d2);
+                const double dist = d2 * rn;
+                dmax = fmax(dmax, dist);
+                ux[k] = dx * rn; uy[k] = dy * rn; uz[k] = dz * rn;
+                // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal; when the product sits
+                // on an integer, the reference's distance and the true division decide
+                const double tq = dist * dinv;
+                double cb = ceil(tq);
+                if (fabs(tq - rint(tq)) < 1e-9 * tq) {
+                    const double vx = (c[0] + dx) - c[0], vy = (c[1] + dy) - c[1], vz = (c[2] + dz) - c[2];
+                    cb = ceil(sqrt(wol_sumsq(vx, vy, vz)) / a.out.dbinwidth);
+                }
+                dbin[k] = (cb >= 1.0 && cb <= (double)a.out.dbins) ? (int)cb - 1 : -1;
             }
             // no component of a neighbour vector reaches 0.49 box lengths if the longest vector stays below 0.49 of
             // the shortest box edge (sufficient; tiny boxes may take the exact path a little more often)
-            emax = dmax * fmax(g.box.ib[0], fmax(g.box.ib[1], g.box.ib[2]));
+            const double emax = dmax * fmax(g.box.ib[0], fmax(g.box.ib[1], g.box.ib[2]));
             // every neighbour inside the smallest cell width is inside the guaranteed radius: the walls only matter beyond
             const double cwmin = fmin(g.cw[0], fmin(g.cw[1], g.cw[2]));
             const double rg = (dmax > cwmin - 1e-4) ? wol_guaranteed_radius(c, g, a.rows) : cwmin;
@@ -616,8 +629,8 @@ k_finish_fast(FastArgs a) {
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = i + 1; j < 4; ++j) {
-                            const double dot = (dx[i] * dx[j] + dy[i] * dy[j]) + dz[i] * dz[j];
-                            const double cs_ = fmin(1.0, fmax(-1.0, dot * (rn[i] * rn[j]))) + (1.0 / 3.0);
+                            const double dot = (ux[i] * ux[j] + uy[i] * uy[j]) + uz[i] * uz[j];
+                            const double cs_ = fmin(1.0, fmax(-1.0, dot)) + (1.0 / 3.0);
                             tm[m++] = cs_ * cs_;
                         }
                 }
@@ -645,17 +658,8 @@ k_finish_fast(FastArgs a) {
                 }
                 if (lds_dh) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal; when the
-                        // product sits on an integer, the reference's distance and the true division decide
-                        const double tq = dist[k] * dinv;
-                        double cb = ceil(tq);
-                        if (fabs(tq - rint(tq)) < 1e-9 * tq) {
-                            const double vx = (c[0] + dx[k]) - c[0], vy = (c[1] + dy[k]) - c[1], vz = (c[2] + dz[k]) - c[2];
-                            cb = ceil(sqrt(wol_sumsq(vx, vy, vz)) / a.out.dbinwidth);
-                        }
-                        if (cb >= 1.0 && cb <= (double)a.out.dbins) atomicAdd(&lds_dh[(int)cb - 1], 1);
-                    }
+                    for (int k = 0; k < 4; ++k)
+                        if (dbin[k] >= 0) atomicAdd(&lds_dh[dbin[k]], 1);
                 }
             }
         } } else if (live && !slow) {
