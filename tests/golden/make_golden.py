@@ -215,9 +215,12 @@ def main():
     fB, boxB = xyzB[0], boxesB[0]
     Ob = fB[0::3].copy(); donB = np.repeat(Ob, 2, axis=0); Hb = np.empty((1200, 3)); Hb[0::2] = fB[1::3]; Hb[1::2] = fB[2::3]
     b1 = wl.generalhbonds(Ob, donB, Hb, boxB, 3.0, 150.0); b2 = wl.generalhbonds(Ob, donB, Hb, boxB, 3.5, 120.0)
+    accI = np.arange(0, 1800, 3); donI = np.repeat(accI, 2); donHI = (donI.reshape(-1, 2) + np.array([1, 2])).reshape(-1)
+    nhb, hbl, hbloc = wp.HBondsGeneral(Ob, donB, Hb, boxB, accI, donI, donHI, distCut=3.5, angCut=120.0)
     np.savez_compressed(os.path.join(OUT, "hbonds600.npz"), acc=Ob, don=donB, donh=Hb, box=boxB,
                         pairs_3p0_150=np.stack(np.where(b1 == 1), axis=1).astype(np.int32),
-                        pairs_3p5_120=np.stack(np.where(b2 == 1), axis=1).astype(np.int32))
+                        pairs_3p5_120=np.stack(np.where(b2 == 1), axis=1).astype(np.int32),
+                        acc_inds=accI, don_inds=donI, donh_inds=donHI, hbg_num=nhb, hbg_list=hbl, hbg_loc=hbloc)
     print("hbonds600          bonds at (3.0 A, 150 deg): %d, at (3.5 A, 120 deg): %d" % (b1.sum(), b2.sum()))
 
 

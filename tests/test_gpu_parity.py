@@ -656,6 +656,14 @@ def test_hbonds_golden_and_oracle(oracle):
         wl.generalhbonds(O, don[:-1], H, boxes[0], 3.0, 150.0)
 
 
+def test_hbonds_general_wrapper(wp):
+    """wp.HBondsGeneral (water_properties.py:681-720) against the reference's own output"""
+    g = golden("hbonds600")
+    n, hl, loc = wp.HBondsGeneral(g["acc"], g["don"], g["donh"], g["box"], g["acc_inds"], g["don_inds"], g["donh_inds"],
+                                  distCut=3.5, angCut=120.0)
+    assert n == int(g["hbg_num"]) and np.array_equal(hl, g["hbg_list"]) and np.array_equal(loc, g["hbg_loc"])
+
+
 def test_bound_wrap_driver(oracle):
     """getBoundWrap (orderParam_lib.py:419-572) on arrays: shell / bound / wrap sets against the same logic run on the
     oracle's masks"""

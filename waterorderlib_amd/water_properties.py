@@ -130,3 +130,23 @@ def waterOrientationBinZ(Opos, Hpos, boxDim, refVec=[0.0, 0.0, 1.0], refBins=Non
     plane2Dhist, _, _ = np.histogram2d(angPlane, zOpos, bins=[angBins, refBins])
     dip2Dhist, _, _ = np.histogram2d(angDip, zOpos, bins=[angBins, refBins])
     return plane2Dhist, dip2Dhist
+
+
+def HBondsGeneral(accPos, donPos, donHPos, boxL, accInds, donInds, donHInds, distCut=3.5, angCut=150.0):
+    """water_properties.py:681-720: (NumHB, HBlist[NumHB,2] = (acceptor index, donor index), HBloc[NumHB,3] = midpoint
+    between the acceptor and the donor hydrogen imaged about it).  The reference scans the (nacc, ndon) mask of
+    wl.generalhbonds row by row; the bonds come from the cell list here (wl.generalhbonds_list, same order)."""
+    accPos = _pos(accPos, "accPos"); donHPos = _pos(donHPos, "donHPos")
+    box = np.asarray(boxL, dtype=np.float64).reshape(-1)[:3]
+    ai, di = wl.generalhbonds_list(accPos, donPos, donHPos, box, distCut, angCut)
+    NumHB = len(ai)
+    HBlist = (-1) * np.ones((NumHB, 2))
+    HBlist[:, 0] = np.asarray(accInds)[ai]
+    HBlist[:, 1] = np.asarray(donInds)[di]
+    a = accPos[ai]
+    d = donHPos[di] - a
+    ibox = np.where(box >= 0.0, 1.0 / np.where(box == 0.0, np.inf, box), 0.0) if np.any(box <= 0.0) else 1.0 / box
+    t = d * ibox
+    d = d - box * (np.sign(t) * np.floor(np.abs(t) + 0.5))     # anint: half away from zero (waterlib.f90:44)
+    HBloc = 0.5 * ((a + d) + a)
+    return NumHB, HBlist, HBloc
