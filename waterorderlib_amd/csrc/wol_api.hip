@@ -108,7 +108,7 @@ struct wol_ctx {
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
-    DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps;
+    DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps, scan_tot;
     PinBuf grids_host;
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
@@ -358,6 +358,8 @@ int collect_timing(wol_ctx* c) {
     return WOL_OK;
 }
 
+int launch_cell_scan(wol_ctx* c, hipStream_t st, const FrameGrid* grids, int* cells, int F, int ncell_max);
+
 struct HistArgs {
     unsigned long long* qhist = nullptr;  // device
     unsigned long long* dhist = nullptr;  // device
@@ -528,7 +530,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
             hipLaunchKernelGGL(k_bin_count<T>, gb, dim3(WOL_BLOCK), 0, ss, fv, S.grids.as<FrameGrid>(),
                                S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
-            hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, ss, S.grids.as<FrameGrid>(), S.cells.as<int>());
+            WOL_TRY(launch_cell_scan(c, ss, S.grids.as<FrameGrid>(), S.cells.as<int>(), F, ncell_max));
             hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, ss, fv, S.grids.as<FrameGrid>(),
                                S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), S.sorted.as<double4>(), s32);
         }
@@ -625,6 +627,21 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     return WOL_OK;
 }
 
+// exclusive scan of the cell counters of F frames (tables of up to ncell_max cells)
+int launch_cell_scan(wol_ctx* c, hipStream_t st, const FrameGrid* grids, int* cells, int F, int ncell_max) {
+    if (ncell_max <= 32768 || ncell_max > 4096 * 1024) {
+        hipLaunchKernelGGL(k_cell_scan, dim3(F), dim3(1024), 0, st, grids, cells);
+        return WOL_OK;
+    }
+    const int ntile = (ncell_max + 4095) / 4096;
+    WOL_TRY(c->scan_tot.ensure(sizeof(int) * (size_t)F * ntile));
+    int* tt = c->scan_tot.as<int>();
+    hipLaunchKernelGGL(k_cell_scan_tiles, dim3(ntile, F), dim3(1024), 0, st, grids, cells, tt, ntile);
+    hipLaunchKernelGGL(k_cell_scan_totals, dim3(F), dim3(1024), 0, st, grids, cells, tt, ntile);
+    hipLaunchKernelGGL(k_cell_scan_add, dim3(ntile, F), dim3(1024), 0, st, grids, cells, tt, ntile);
+    return WOL_OK;
+}
+
 // Single-frame set-up shared by wol_cos_angs / wol_lsi_frame: upload, bin, cell-sort; the grid is
 // built for the given reach so walking cells [-lo, hi]^3 sees every neighbour inside it.
 int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
@@ -660,7 +677,7 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
     const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, 1);
     hipLaunchKernelGGL(k_bin_count<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, S.grids.as<FrameGrid>(),
                        S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
-    hipLaunchKernelGGL(k_cell_scan, dim3(1), dim3(1024), 0, c->stream, S.grids.as<FrameGrid>(), S.cells.as<int>());
+    WOL_TRY(launch_cell_scan(c, c->stream, S.grids.as<FrameGrid>(), S.cells.as<int>(), 1, gh->ncell));
     hipLaunchKernelGGL(k_scatter<double>, gb, dim3(WOL_BLOCK), 0, c->stream, fv, S.grids.as<FrameGrid>(),
                        S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), S.sorted.as<double4>(),
                        (float4*)nullptr);
@@ -841,7 +858,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->cellid, &c->rank, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps, &c->scan_tot};
     for (auto& S : c->sets) {
         S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release();
         if (S.sorted_ev) (void)hipEventDestroy(S.sorted_ev);

@@ -82,6 +82,72 @@ k_cell_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count) {
     if (tid == 0) c[ncell] = carry;
 }
 
+// The same scan for big tables (a 500k-water frame binned for a short reach has ~0.5 M cells): every tile of 4096
+// gets its own block (local scan + tile total), one block per frame scans the tile totals, a third launch adds them.
+__global__ void __launch_bounds__(1024)
+k_cell_scan_tiles(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count, int* __restrict__ tile_tot, int tt_stride) {
+    __shared__ int wsum[16];
+    const FrameGrid& g = grids[blockIdx.y];
+    int* c = cell_count + g.cell_base;
+    const int ncell = g.ncell, t0 = blockIdx.x * 4096;
+    if (t0 >= ncell) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = t0 + 4 * tid;
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (i + u < ncell) ? c[i + u] : 0;
+    const int s = (v[0] + v[1]) + (v[2] + v[3]);
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int x = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += x;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int x = wsum[w]; total += x; if (w < wave) before += x; }
+    int run = before + inc - s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { if (i + u < ncell) c[i + u] = run; run += v[u]; }
+    if (tid == 0) tile_tot[(int64_t)blockIdx.y * tt_stride + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024)
+k_cell_scan_totals(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count, int* __restrict__ tile_tot, int tt_stride) {
+    __shared__ int wsum[16];
+    const FrameGrid& g = grids[blockIdx.x];
+    int* tt = tile_tot + (int64_t)blockIdx.x * tt_stride;
+    const int ntile = (g.ncell + 4095) / 4096;   // <= 1024 tiles: 4 M cells
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v = tid < ntile ? tt[tid] : 0;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int x = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += x;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int x = wsum[w]; total += x; if (w < wave) before += x; }
+    if (tid < ntile) tt[tid] = before + inc - v;
+    if (tid == 0) cell_count[g.cell_base + g.ncell] = total;
+}
+
+__global__ void __launch_bounds__(1024)
+k_cell_scan_add(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count, const int* __restrict__ tile_tot, int tt_stride) {
+    const FrameGrid& g = grids[blockIdx.y];
+    const int add = tile_tot[(int64_t)blockIdx.y * tt_stride + blockIdx.x];
+    int* c = cell_count + g.cell_base;
+    const int i = blockIdx.x * 4096 + 4 * threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (i + u < g.ncell) c[i + u] += add;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start,
