@@ -48,3 +48,39 @@ def test_two_rank_reduction_matches_single(oracle, T):
         assert np.array_equal(m, mean) and np.array_equal(v, var)
         assert np.array_equal(q, qh) and np.array_equal(d, dh)
         assert q.dtype == np.int64 and d.sum() == 4 * n * T
+
+
+def _gpu_worker(rank, world, port, T, n, ret):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from waterorderlib_amd import engine, synth
+        xyz, boxes = synth.water_frames(n, T, seed=9)
+        a, b = engine.shard_bounds(T, rank, world)
+        tot = engine.tet_order_traj_sharded(xyz[a:b], boxes[a:b], T_total=T, frame_offset=a)
+        out = [np.asarray(tot.mean), np.asarray(tot.var), np.asarray(tot.qhist), np.asarray(tot.dhist)]
+        if rank == 0:
+            one = engine.tet_order_traj(xyz, boxes)
+            out += [np.asarray(one.mean), np.asarray(one.var), np.asarray(one.qhist), np.asarray(one.dhist)]
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_match_the_unsharded_run():
+    """the frame-sharded product path end to end: two processes (sharing the one GPU of the test box), libwol on
+    each shard, the exchange step over gloo; every rank ends with the unsharded result, bit for bit"""
+    n, T, world = 4000, 130, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gpu_worker, args=(world, port, T, n, ret), nprocs=world, join=True)
+    ref = ret[0][4:]
+    for r in range(world):
+        for got, want in zip(ret[r][:4], ref):
+            assert np.array_equal(got, want)
+    assert ref[3].sum() == 4 * n * T
