@@ -54,12 +54,16 @@ int wol_ctx_destroy(wol_ctx* ctx);
  * stream is.  Cheap when the stream is unchanged. */
 int wol_ctx_set_stream(wol_ctx* ctx, void* hip_stream);
 int wol_ctx_synchronize(wol_ctx* ctx);
-/* tunables: "cell_width" (A, default 4.5), "frames_per_batch", "path" (0 auto, 1 force brute-force,
- * 2 force exact cell kernel, 3 force filtered cell kernel), "lds_sort" (1 = per-frame counting sort
- * in LDS when it fits, 0 = global-atomic form), "overlap" (1 = sort the next batch on a second stream beside
- * the current batch's search; default 0: measured no gain), "inputs_resident" (1 = the caller guarantees that device input buffers are
- * complete in memory when a call is made, not merely enqueued earlier on the stream, so the sort of one call
- * may overlap the previous call's kernels; default 0), "time_kernels" (0/1) */
+/* tunables: "cell_width" (A, default 4.5), "frames_per_batch" (0 = automatic), "path" (0 auto, 1 force
+ * all-pairs, 2 force exact cell kernel, 3 force filtered cell kernel), "search_rows" (1 = row-merged proposal
+ * kernel, default; 0 = 3-D tile proposal kernel), "lds_sort" (1 = streaming / LDS sorts when they apply,
+ * default; 0 = global-atomic form), "sort_parts" (blocks per frame of the streaming sort's first level, 0 =
+ * automatic), "overlap" (1 = sort the next batch on a second stream beside the current batch's search;
+ * default 0: measured +0-5 %), "search_margin" (blocks per CU the proposal kernel leaves free for such an
+ * overlapped sort), "inputs_resident" (1 = the caller guarantees that device input buffers are complete in
+ * memory when a call is made, not merely enqueued earlier on the stream, so the sort of one call may overlap
+ * the previous call's kernels; default 0), "time_kernels" (0/1: HIP-event timing of the dominant kernel,
+ * read back with wol_ctx_kernel_time) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
