@@ -177,6 +177,7 @@ def main():
     k_ms, k_launches = ctx.kernel_time(reset=False)
     slow_last = ctx.counter("slow_waters")
     dens_level = ctx.counter("density_level")
+    rows_block = ctx.counter("rows_block")
 
     if rank == 0:
         traffic = args.traffic_bytes
@@ -214,7 +215,7 @@ def main():
                          "traffic": traffic,
                          "launches": int(k_launches), "avg_launch_ms": k_avg_s * 1e3,
                          "exact_path_fraction_last_launch": slow_last / float(F * n),
-                         "tile_density_level": dens_level,
+                         "tile_density_level": dens_level, "proposal_block_threads": rows_block,
                          "alg_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 of the one-GPU run only

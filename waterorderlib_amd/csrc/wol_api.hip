@@ -105,6 +105,7 @@ struct wol_ctx {
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
     size_t sort_rows_lds_set = 0;
+    int last_rows_block = 0;
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
@@ -131,23 +132,24 @@ Box3 make_box(const double* box) {
 
 // Builds the uniform grid of one frame.  Returns false when the frame must take the all-pairs
 // path: a non-periodic axis (BoxL < 0), BoxL == 0 or a non-finite length.
-bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g);
+bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block);
 
 // trajectories at constant volume repeat one box: keep the last grid
-bool make_grid(const double* box, int n, double cell_width, double high, FrameGrid* g) {
-    static thread_local struct { double box[3], cw, high; int n; bool ok, valid = false; FrameGrid g; } last;
+// rows_block: k_search_rows instantiation to size the row tiles for (512 or 768); 0 = whichever fills its lanes better
+bool make_grid(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block = 0) {
+    static thread_local struct { double box[3], cw, high; int n, rb; bool ok, valid = false; FrameGrid g; } last;
     if (last.valid && last.n == n && last.cw == cell_width && last.high == high && last.box[0] == box[0] &&
-        last.box[1] == box[1] && last.box[2] == box[2]) {
+        last.box[1] == box[1] && last.box[2] == box[2] && last.rb == rows_block) {
         *g = last.g;
         return last.ok;
     }
-    const bool ok = make_grid_uncached(box, n, cell_width, high, g);
+    const bool ok = make_grid_uncached(box, n, cell_width, high, g, rows_block);
     last.box[0] = box[0]; last.box[1] = box[1]; last.box[2] = box[2];
-    last.cw = cell_width; last.high = high; last.n = n; last.ok = ok; last.g = *g; last.valid = true;
+    last.cw = cell_width; last.high = high; last.n = n; last.rb = rows_block; last.ok = ok; last.g = *g; last.valid = true;
     return ok;
 }
 
-bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g) {
+bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block) {
     g->box = make_box(box);
     g->maxshell = -1;
     g->ncell = 1;
@@ -187,7 +189,7 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
     g->nlev = 0;
     g->ntiles = 0;
     g->scale = 1.f; g->tmax = 0.f; g->S = 1.0; g->eps_units = 0;
-    g->row_tiles_max = 0; g->row_eps_units = 0;
+    g->row_tiles_max = 0; g->row_eps_units = 0; g->row_block = WOL_ROWS_BLOCK_A;
     if (g->nc[0] >= 3 && g->nc[1] >= 3 && g->nc[2] >= 3) {
         const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
@@ -256,36 +258,52 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
 
         // ---- tiles of the row-merged kernel (wol_search_rows.hip): sx cells x ry rows in one z layer;
         //      staged = (ry + 2) triples of three z rows, sx + 2 cells long ----
+        // the tile search for one instantiation (block threads, capp staged pairs); returns the lane fill at level 0
+        struct RowTiles { short sx[WOL_NLEV], ry[WOL_NLEV], ntx[WOL_NLEV], nty[WOL_NLEV]; double fill0; };
+        auto row_tiles = [&](int block, int capp, RowTiles* rt) {
+            const int target = WOL_ROWS_TARGET(block);
+            for (int l = 0; l < WOL_NLEV; ++l) {
+                const double w = wpc * lev_mult[l] / 1.10;
+                double best = -1.0, bq = 0.0;
+                int bsx = 1, bry = 1, bntx = g->nc[0], bnty = g->nc[1];
+                for (int sx0 = 1; sx0 <= std::min(g->nc[0], WOL_ROWS_MAXSX); ++sx0) {
+                    const int ntx = (g->nc[0] + sx0 - 1) / sx0, sx = (g->nc[0] + ntx - 1) / ntx;  // equalised
+                    if (sx != sx0) continue;
+                    for (int ry0 = 1; ry0 <= std::min(g->nc[1], WOL_ROWS_MAXRY); ++ry0) {
+                        const int nty = (g->nc[1] + ry0 - 1) / ry0, ry = (g->nc[1] + nty - 1) / nty;
+                        if (ry != ry0) continue;
+                        const double q = sx * ry * w;
+                        const bool unit = (sx == 1 && ry == 1);
+                        if (q > (double)target && !unit) continue;
+                        const double staged = 3.0 * (ry + 2) * (sx + 2) * w;
+                        if (staged * 1.12 + (ry + 2) > 2.0 * capp && !unit) continue;
+                        if ((ry + 2) * (((sx + 2) * WOL_XSUB + 2) / 2) > WOL_ROWS_BINW) continue;
+                        // fill of the block's lanes first (5 % bands), then the staging ratio
+                        const double band = std::floor(q / (0.05 * target));
+                        const double score = band - staged / (q * 100.0);
+                        if (score > best) { best = score; bsx = sx; bry = ry; bntx = ntx; bnty = nty; bq = q; }
+                    }
+                }
+                rt->sx[l] = (short)bsx; rt->ry[l] = (short)bry; rt->ntx[l] = (short)bntx; rt->nty[l] = (short)bnty;
+                if (l == 0) rt->fill0 = bq / (double)block;
+            }
+        };
+        RowTiles rta, rtb;
+        row_tiles(WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A, &rta);
+        row_tiles(WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B, &rtb);
+        // three 512-thread blocks per CU overlap their staging phases better than two of 768: the larger block has to
+        // win clearly on lane fill
+        const bool use_b = rows_block ? rows_block == WOL_ROWS_BLOCK_B : rtb.fill0 > rta.fill0 + 0.06;
+        const RowTiles& rt = use_b ? rtb : rta;
+        g->row_block = use_b ? WOL_ROWS_BLOCK_B : WOL_ROWS_BLOCK_A;
         g->row_tiles_max = 0;
         int rmax_sx = 1, rmax_ry = 1;
         for (int l = 0; l < WOL_NLEV; ++l) {
-            const double w = wpc * lev_mult[l] / 1.10;
-            double best = -1.0;
-            int bsx = 1, bry = 1, bntx = g->nc[0], bnty = g->nc[1];
-            for (int sx0 = 1; sx0 <= std::min(g->nc[0], WOL_ROWS_MAXSX); ++sx0) {
-                const int ntx = (g->nc[0] + sx0 - 1) / sx0, sx = (g->nc[0] + ntx - 1) / ntx;  // equalised
-                if (sx != sx0) continue;
-                for (int ry0 = 1; ry0 <= std::min(g->nc[1], WOL_ROWS_MAXRY); ++ry0) {
-                    const int nty = (g->nc[1] + ry0 - 1) / ry0, ry = (g->nc[1] + nty - 1) / nty;
-                    if (ry != ry0) continue;
-                    const double q = sx * ry * w;
-                    const bool unit = (sx == 1 && ry == 1);
-                    if (q > (double)WOL_ROWS_TARGET && !unit) continue;
-                    const double staged = 3.0 * (ry + 2) * (sx + 2) * w;
-                    if (staged * 1.12 + (ry + 2) > 2.0 * WOL_ROWS_CAPP && !unit) continue;
-                    if ((ry + 2) * (((sx + 2) * WOL_XSUB + 2) / 2) > WOL_ROWS_BINW) continue;
-                    // fill of the block's lanes first (5 % bands), then the staging ratio
-                    const double band = std::floor(q / (0.05 * WOL_ROWS_TARGET));
-                    const double score = band - staged / (q * 100.0);
-                    if (score > best) { best = score; bsx = sx; bry = ry; bntx = ntx; bnty = nty; }
-                }
-            }
-            g->row_sx[l] = (short)bsx; g->row_ry[l] = (short)bry;
-            g->row_ntx[l] = (short)bntx; g->row_nty[l] = (short)bnty;
-            g->row_ntiles[l] = bntx * bnty * g->nc[2];
+            g->row_sx[l] = rt.sx[l]; g->row_ry[l] = rt.ry[l]; g->row_ntx[l] = rt.ntx[l]; g->row_nty[l] = rt.nty[l];
+            g->row_ntiles[l] = rt.ntx[l] * rt.nty[l] * g->nc[2];
             g->row_tiles_max = std::max(g->row_tiles_max, g->row_ntiles[l]);
-            rmax_sx = std::max(rmax_sx, bsx);
-            rmax_ry = std::max(rmax_ry, bry);
+            rmax_sx = std::max(rmax_sx, (int)rt.sx[l]);
+            rmax_ry = std::max(rmax_ry, (int)rt.ry[l]);
         }
         {
             // per-axis coordinate magnitudes: x up to half the staged tile length, y half the staged rows
@@ -388,10 +406,12 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     int n_cell_frames = 0;
     std::vector<int> brute_frames;
     const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
+    int rows_block = 0;   // the k_search_rows instantiation of this batch: the first frame's choice
     for (int f = 0; f < F; ++f) {
-        bool ok = !force_brute && make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f]);
+        bool ok = !force_brute && make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f], rows_block);
+        if (ok && rows_block == 0) rows_block = gh[f].row_block;
         if (!ok) {
-            make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f]);
+            make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f], rows_block);
             gh[f].maxshell = -1;  // search kernel skips this frame
             gh[f].ncell = 1;
             for (int k = 0; k < 3; ++k) gh[f].nc[k] = 1;
@@ -586,11 +606,15 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
 #endif
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = 0;
-            if (rows_kernel) WOL_TRY(resident_grid(c, k_search_rows, WOL_ROWS_BLOCK, 0, ftotal, &fgrid, c->search_margin));
+            const bool rows_b = rows_block == WOL_ROWS_BLOCK_B;
+            c->last_rows_block = rows_kernel ? rows_block : 0;
+            if (rows_kernel && rows_b) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>, WOL_ROWS_BLOCK_B, 0, ftotal, &fgrid, c->search_margin));
+            else if (rows_kernel) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>, WOL_ROWS_BLOCK_A, 0, ftotal, &fgrid, c->search_margin));
             else WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-            if (rows_kernel) hipLaunchKernelGGL(k_search_rows, dim3(fgrid), dim3(WOL_ROWS_BLOCK), 0, c->stream, fa);
+            if (rows_kernel && rows_b) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_B), 0, c->stream, fa);
+            else if (rows_kernel) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_A), 0, c->stream, fa);
             else hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
             const int64_t wtotal = (int64_t)F * n;
@@ -941,6 +965,10 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
             HIP_TRY(hipMemcpy(&v, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost));
             *value = v;
         }
+        return WOL_OK;
+    }
+    if (std::string(key) == "rows_block") {  // k_search_rows instantiation of the last batch (threads per block)
+        *value = c->last_rows_block;
         return WOL_OK;
     }
     if (std::string(key) == "density_level") {  // tile-shape level of frame 0 of the last batch

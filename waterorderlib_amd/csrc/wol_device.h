@@ -40,6 +40,7 @@ struct FrameGrid {
     short row_sx[WOL_NLEV], row_ry[WOL_NLEV], row_ntx[WOL_NLEV], row_nty[WOL_NLEV];
     int row_ntiles[WOL_NLEV];
     int row_tiles_max;
+    int row_block;      // threads of the k_search_rows instantiation these tiles were sized for (512 or 768)
     int row_eps_units;  // its bound on |fp32 key - exact d^2 * S| (longer tiles: larger coordinates)
     float row_eps_a, row_eps_b;  // the same bound at distance d: a * sqrt(d^2 in key units) + b
     float scale;        // sqrt(S): staged coordinates are multiplied by it so d^2 comes out in key units

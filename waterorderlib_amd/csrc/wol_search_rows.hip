@@ -21,12 +21,13 @@
 // record (d2 = 0) leaves the [2^23, 2^24) binade and its key reads as saturated; every other key is d2 - 1.
 #pragma once
 
-#ifndef WOL_ROWS_BLOCK
-#define WOL_ROWS_BLOCK 512
-#endif
-#ifndef WOL_ROWS_CAPP
-#define WOL_ROWS_CAPP 1280     // staged PAIRS per tile (with the tables: < 53 KiB of LDS, three blocks per CU)
-#endif
+// Two instantiations: 512 threads / 1280 staged pairs (49 KiB of LDS, three blocks per CU) and 768 threads / 1920
+// pairs (71 KiB, two blocks per CU: the same 24 waves).  The host picks per batch the one whose tiles fill their lanes
+// better: a 10 000-water box has 714 waters per cell layer -- 70 % of two 512-lane sweeps, 93 % of 768 lanes.
+#define WOL_ROWS_BLOCK_A 512
+#define WOL_ROWS_CAPP_A 1280
+#define WOL_ROWS_BLOCK_B 768
+#define WOL_ROWS_CAPP_B 1920
 #define WOL_ROWS_PADP 8        // head-room pairs behind the last triple (incl. the dummy pair)
 #ifndef WOL_XSUB
 #define WOL_XSUB 4             // fine x bins per cell
@@ -37,7 +38,7 @@
 #define WOL_ROWS_MAXSX (252 / WOL_XSUB - 2)   // (sx + 2) * XSUB bins <= 252 (four bins per lane in the scan)
 #define WOL_ROWS_BINW 704      // 32-bit words of bin counters: sum over the triples of ceil((bins + 1) / 2)
 #define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
-#define WOL_ROWS_TARGET ((WOL_ROWS_BLOCK * 97) / 100)
+#define WOL_ROWS_TARGET(block) (((block) * 97) / 100)
 #ifndef WOL_ROWS_WPS
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
 #endif
@@ -46,7 +47,7 @@
 // Records are split in two arrays of 16-byte halves, A = (x0, x1, y0, y1) and B = (z0, z1, id0, id1) per pair:
 // a ds_read_b128 is served in groups of 16 lanes that conflict on (address / 16) mod 16, and consecutive pairs of
 // one array fall on consecutive classes (interleaved 32-byte records would use every other class only).
-#define WOL_ROWS_B_OFF (16 * (WOL_ROWS_CAPP + WOL_ROWS_PADP))   // byte offset of array B behind array A
+template <int B_OFF>   // byte offset of array B behind array A
 __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes, int pb, int np, int dummy_off,
                                               wol_f2 xi, wol_f2 yi, wol_f2 zi, unsigned tmaxbits, unsigned& k0,
                                               unsigned& k1, unsigned& k2, unsigned& k3, unsigned& k4) {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes
     for (int t = 0; t < T; ++t, off += 16) {
         const int o = (off < end) ? off : dummy_off;
         const float4 a = *reinterpret_cast<const float4*>(rec_bytes + o);
-        const float4 b = *reinterpret_cast<const float4*>(rec_bytes + o + WOL_ROWS_B_OFF);
+        const float4 b = *reinterpret_cast<const float4*>(rec_bytes + o + B_OFF);
         const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
         wol_f2 tt = __builtin_elementwise_fma(dx, dx, bias);
         tt = __builtin_elementwise_fma(dy, dy, tt);
@@ -79,7 +80,8 @@ __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes
     }
 }
 
-__global__ void __launch_bounds__(WOL_ROWS_BLOCK, WOL_ROWS_WPS)
+template <int WOL_ROWS_BLOCK, int WOL_ROWS_CAPP>
+__global__ void __launch_bounds__(WOL_ROWS_BLOCK, WOL_ROWS_WPS)   // 6 waves per SIMD either way: 3 x 8 or 2 x 12 waves per CU
 k_search_rows(FastArgs a) {
     __shared__ float4 rec[2 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)];  // pair records: array A (x0,x1,y0,y1), then array B (z0,z1,id0,id1)
     __shared__ unsigned char rkb[2 * WOL_ROWS_CAPP];             // staged water (row order) -> rank inside its bin
@@ -351,7 +353,7 @@ k_search_rows(FastArgs a) {
 #ifdef WOL_EXP_NO_SWEEP   // ablation build: timing only, results are wrong
                     k0 ^= win[dt];
 #else
-                    wol_rows_span(reinterpret_cast<const char*>(rec), (int)(win[dt] & 0xFFFFu), (int)(win[dt] >> 16), dummy_p * 16,
+                    wol_rows_span<16 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)>(reinterpret_cast<const char*>(rec), (int)(win[dt] & 0xFFFFu), (int)(win[dt] >> 16), dummy_p * 16,
                                   xi, yi, zi, tmaxbits, k0, k1, k2, k3, k4);
 #endif
                 }
