@@ -547,10 +547,14 @@ k_finish_fast(FastArgs a) {
     // frames <-> XCDs as in the proposal kernel, so a frame's sorted array is read through one L2
     const bool aff = a.xcd_affine != 0;
     const int fstep = aff ? 8 : 1;
-    const int kb = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int KB = aff ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    int kb = aff ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int KB = aff ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    // small frames need fewer blocks than a group has: the group then works on several frames at a time
+    const int need = (a.n + WOL_BLOCK - 1) / WOL_BLOCK;
+    int fsub = 0, fgroups = 1;
+    if (need < KB) { fgroups = KB / need; fsub = kb / need; kb -= fsub * need; KB = need; }
     __shared__ unsigned long long blk_stat[4];
-    for (int f = aff ? (int)(blockIdx.x & 7) : 0; f < a.F; f += fstep) {
+    for (int f = (aff ? (int)(blockIdx.x & 7) : 0) + fstep * fsub; f < a.F && fsub < fgroups; f += fstep * fgroups) {
     long long sum_h = 0, sum_l = 0, sum_h2 = 0, sum_l2 = 0;  // this lane's share of frame f's sums of q, q^2
     for (int s0 = kb * WOL_BLOCK; s0 < a.n; s0 += KB * WOL_BLOCK) {  // uniform bounds: whole waves stay in the loop
         const int s = min(s0 + (int)threadIdx.x, a.n - 1);
