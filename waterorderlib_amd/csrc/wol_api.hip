@@ -488,7 +488,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         }
         const bool big_rows = nrow_max > WOL_L1_MAXROWS;
         int P = 1;
-        if (layer_sort && (F < 64 || big_rows)) {
+        if (layer_sort && (5 * F < 3 * c->num_cus || big_rows)) {   // fewer frames than ~0.6 blocks per CU: split them
             P = std::min(64, std::max(1, (2 * c->num_cus + F - 1) / F));          // about two blocks per CU
             P = std::min(P, std::max(1, n / (4 * WOL_SORT_BLOCK)));                  // at least a few chunks each
             if (P == 1 && big_rows) P = 2;                                           // the fused kernel's tables end at MAXROWS
