@@ -293,9 +293,9 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
         row_tiles(WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B, &rtb);
         // three 512-thread blocks per CU overlap their staging phases better than two of 768: the larger block has to
         // win clearly on lane fill
-        const bool use_b = rows_block ? rows_block == WOL_ROWS_BLOCK_B : rtb.fill0 > rta.fill0 + 0.06;
-        const RowTiles& rt = use_b ? rtb : rta;
-        g->row_block = use_b ? WOL_ROWS_BLOCK_B : WOL_ROWS_BLOCK_A;
+        const int pick = rows_block ? rows_block : (rtb.fill0 > rta.fill0 + 0.06 ? WOL_ROWS_BLOCK_B : WOL_ROWS_BLOCK_A);
+        const RowTiles& rt = pick == WOL_ROWS_BLOCK_B ? rtb : rta;
+        g->row_block = pick;
         g->row_tiles_max = 0;
         int rmax_sx = 1, rmax_ry = 1;
         for (int l = 0; l < WOL_NLEV; ++l) {
@@ -606,16 +606,15 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
 #endif
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = 0;
-            const bool rows_b = rows_block == WOL_ROWS_BLOCK_B;
             c->last_rows_block = rows_kernel ? rows_block : 0;
-            if (rows_kernel && rows_b) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>, WOL_ROWS_BLOCK_B, 0, ftotal, &fgrid, c->search_margin));
-            else if (rows_kernel) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>, WOL_ROWS_BLOCK_A, 0, ftotal, &fgrid, c->search_margin));
-            else WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
+            if (!rows_kernel) WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
+            else if (rows_block == WOL_ROWS_BLOCK_B) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>, WOL_ROWS_BLOCK_B, 0, ftotal, &fgrid, c->search_margin));
+            else WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>, WOL_ROWS_BLOCK_A, 0, ftotal, &fgrid, c->search_margin));
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-            if (rows_kernel && rows_b) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_B), 0, c->stream, fa);
-            else if (rows_kernel) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_A), 0, c->stream, fa);
-            else hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
+            if (!rows_kernel) hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
+            else if (rows_block == WOL_ROWS_BLOCK_B) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_B), 0, c->stream, fa);
+            else hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_A), 0, c->stream, fa);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
             const int64_t wtotal = (int64_t)F * n;
             int ggrid = 0;

@@ -22,8 +22,10 @@
 #pragma once
 
 // Two instantiations: 512 threads / 1280 staged pairs (49 KiB of LDS, three blocks per CU) and 768 threads / 1920
-// pairs (71 KiB, two blocks per CU: the same 24 waves).  The host picks per batch the one whose tiles fill their lanes
-// better: a 10 000-water box has 714 waters per cell layer -- 70 % of two 512-lane sweeps, 93 % of 768 lanes.
+// pairs (71 KiB, two blocks per CU: the same 24 waves).  A tile lives in one cell layer, so small boxes quantise badly;
+// the host picks per batch the instantiation whose tiles fill their lanes better: a 10 000-water box has 714 waters
+// per layer -- two tiles of 357 for 512 lanes, one of 714 for 768 (fewer halo rows, half the per-tile work).  (A
+// 384-thread form for still smaller boxes was measured slower: idle waves of a half-empty tile cost little.)
 #define WOL_ROWS_BLOCK_A 512
 #define WOL_ROWS_CAPP_A 1280
 #define WOL_ROWS_BLOCK_B 768
