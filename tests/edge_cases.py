@@ -1,0 +1,106 @@
+"""Constructed inputs that sit on a decision boundary of an INTEGER output, built with the CPU oracle (test
+infrastructure): a frame in which chosen waters have q within ~1e-15 of a histogram bin edge, and acceptor / donor / hydrogen
+triples whose D-H...A angle is within one unit in the last place of the hydrogen-bond cut-off angle.  The GPU path must
+take the reference's side of every one of them (bin, bond) -- that is what "bit-exact by construction" means for these
+outputs; a merely accurate q or angle flips about a third of them."""
+import numpy as np
+
+
+def _bisect_coordinate(f, lo, hi, target, iters=200):
+    """adjacent doubles (a, b) between lo and hi with f(a) < target <= f(b) or f(a) >= target > f(b); f is evaluated
+    with the oracle (the reference's arithmetic), so the pair brackets the reference's own flip"""
+    flo, fhi = f(lo), f(hi)
+    if not ((flo < target) != (fhi < target)):
+        return None
+    for _ in range(iters):
+        mid = 0.5 * (lo + hi)
+        if mid == lo or mid == hi:
+            break
+        fm = f(mid)
+        if (fm < target) == (flo < target):
+            lo, flo = mid, fm
+        else:
+            hi, fhi = mid, fm
+    return lo, hi
+
+
+def frames_with_q_on_bin_edges(oracle, n=6000, n_targets=40, seed=5, qbins=500):
+    """Returns (frames[2, n, 3], boxes[2, 3], targets, edges): two frames that differ only in the last bits of one
+    coordinate of one neighbour per target water, chosen so that the oracle's q of target k lies just below its bin
+    edge in one frame and on / just above it in the other."""
+    from waterorderlib_amd import synth
+    xyz, boxes = synth.water_frames(n, 1, seed=seed)
+    pos, box = xyz[0].copy(), boxes[0]
+    q, idx, dist, _ = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    rng = np.random.default_rng(seed)
+    order = rng.permutation(n)
+    lo_frame, hi_frame = pos.copy(), pos.copy()
+    used = np.zeros(n, dtype=bool)
+    targets, edges = [], []
+    for w in order:
+        if len(targets) == n_targets:
+            break
+        nb = int(idx[w, 0])
+        # keep targets apart: moving one neighbour must not disturb another target's neighbourhood
+        d = pos - pos[w]
+        d -= box * np.round(d / box)
+        near = np.where((d ** 2).sum(axis=1) < 8.0 ** 2)[0]
+        if nb < 0 or used[near].any() or not (0.05 < q[w] < 0.95) or dist[w, 3] > 3.6:
+            continue
+        x0 = pos[nb, 0]
+
+        def q_of(x, w=w, nb=nb):
+            p = lo_frame.copy()   # (targets already placed in lo_frame are far away: their q is unaffected)
+            p[nb, 0] = x
+            return float(oracle.getOrderParamq(p[w:w + 1], p, box)[0])
+
+        found = None
+        for delta in (0.02, 0.05):
+            qa, qb = q_of(x0 - delta), q_of(x0 + delta)
+            k_lo, k_hi = sorted((int(np.floor(qa * qbins)), int(np.floor(qb * qbins))))
+            for k in range(k_lo + 1, k_hi + 1):
+                edge = np.linspace(0.0, 1.0, qbins + 1)[k]    # np.histogram's own edge value
+                br = _bisect_coordinate(q_of, x0 - delta, x0 + delta, edge)
+                if br is not None:
+                    found = (br, edge)
+                    break
+            if found:
+                break
+        if not found:
+            continue
+        (xa, xb), edge = found
+        lo_frame[nb, 0], hi_frame[nb, 0] = xa, xb
+        used[near] = True
+        targets.append(int(w)); edges.append(edge)
+    return np.stack([lo_frame, hi_frame]), np.stack([box, box]), np.array(targets), np.array(edges)
+
+
+def hbond_triples_on_the_cut(oracle, n=200, angcut=150.0, distcut=3.5, seed=9, box=(30.0, 31.0, 29.0)):
+    """acceptors[2n,3], donors[2n,3], hydrogens[2n,3]: pair (i, i) of rows 2k and 2k+1 differ in the last bit of one
+    hydrogen coordinate and the oracle's generalhbonds decision differs between them (angle on either side of the
+    cut).  Pairs (i, j != i) are far apart (no bond)."""
+    rng = np.random.default_rng(seed)
+    box = np.asarray(box, dtype=np.float64)
+    acc, don, hyd = [], [], []
+    k = 0
+    while len(acc) < 2 * n:
+        k += 1
+        d = rng.random(3) * box                       # donor heavy atom
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        h = d + 0.9572 * u                              # its hydrogen
+        v = rng.normal(size=3); v -= u * (u @ v); v /= np.linalg.norm(v)
+        th = np.deg2rad(180.0 - angcut)                 # acceptor direction seen from H, at the cut angle to D-H
+        a = h + 1.9 * (np.cos(th) * u + np.sin(th) * v)
+        a = a + rng.integers(-2, 3, size=3) * box      # some periodic image of it: minimum-image arithmetic is exercised too
+
+        def bonded(x, a=a, d=d, h=h):
+            hh = h.copy(); hh[0] = x
+            return float(oracle.generalhbonds(a[None], d[None], hh[None], box, distcut, angcut)[0, 0])
+
+        br = _bisect_coordinate(bonded, h[0] - 0.01, h[0] + 0.01, 0.5)
+        if br is None:
+            continue
+        for x in br:
+            hh = h.copy(); hh[0] = x
+            acc.append(a); don.append(d); hyd.append(hh)
+    return np.array(acc), np.array(don), np.array(hyd), box

@@ -1,0 +1,202 @@
+"""Round-2 GPU parity tests (all through the C ABI):
+  * integer outputs bit-exact BY CONSTRUCTION: the trajectory mode's q histogram on inputs whose q sits within 1e-15 of
+    a bin edge, hydrogen-bond decisions with the angle within one ulp of the cut (tests/edge_cases.py builds both with the
+    oracle), and lean qhist == np.histogram of the full-chain q on frames of the BASELINE config-3 box;
+  * BASELINE config 2 (10 000 waters x 1 000 frames, fp64) at full length on every instantiation of the proposal
+    kernel, the instantiation forced and asserted;
+  * strided O-row gather against the reference's golden TIP4P frame;
+  * breathing boxes (NPT) through the memoised tile tables."""
+import numpy as np
+import pytest
+
+import edge_cases
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+Q_TOL = 1e-12
+
+
+def _np_hist(q, bins=500):
+    return np.histogram(q, bins=bins, range=[0.0, 1.0], density=False)[0].astype(np.int64)
+
+
+def test_q_on_bin_edges_is_binned_as_the_full_chain_bins_it(oracle):
+    """Every target water's q is within ~1e-15 of an np.histogram edge (adjacent doubles of one coordinate put it just
+    below the edge in one frame, on / above it in the other, in the reference's arithmetic).  The trajectory mode forms q
+    without the acos -> degrees -> cos round trip (|dq| < 2e-14): unguarded, about half of these would be binned on the
+    wrong side.  By construction the integer histogram is np.histogram of the library's own full-chain q
+    (wp.getOrderParamq(full=True): the reference's operation order, device libm); against the reference itself that q can
+    differ in the last place (acos / cos of the device vs the host's libm), so only targets further than 5e-16 from
+    their edge are required to fall in the reference's bin."""
+    from waterorderlib_amd import _lib, engine
+    from waterorderlib_amd import water_properties as wp
+    frames, boxes, targets, edges = edge_cases.frames_with_q_on_bin_edges(oracle)
+    assert len(targets) >= 20
+    ctx = _lib.Context(0)
+    ctx.set_option("path", 3)          # the fp32-filtered cell path (the one trajectories of real boxes take)
+    res = engine.tet_order_traj(frames, boxes, want_q=True, ctx=ctx)
+    assert ctx.counter("slow_waters") >= 2 * len(targets)    # the guard handed them to the exact kernel
+    expect = np.zeros(500, dtype=np.int64)
+    lin = np.linspace(0.0, 1.0, 501)
+    fragile = 0
+    for f in range(2):
+        q_full = wp.getOrderParamq(frames[f], frames[f], boxes[f], full=True, ctx=ctx)[0]
+        expect += _np_hist(q_full)
+        assert np.array_equal(res.q[f][targets], q_full[targets])          # the exact kernel's q, bit for bit
+        np.testing.assert_allclose(res.q[f], q_full, rtol=0, atol=1e-13)
+        q_ref = oracle.getOrderParamq(frames[f], frames[f], boxes[f], cells=True)     # the reference's chain, host libm
+        assert np.max(np.abs(q_ref[targets] - edges)) < 5e-15
+        np.testing.assert_allclose(q_full, q_ref, rtol=0, atol=Q_TOL)
+        clear = np.abs(q_ref[targets] - edges) > 5e-16
+        fragile += int((~clear).sum())
+        assert np.array_equal(np.digitize(q_full[targets][clear], lin), np.digitize(q_ref[targets][clear], lin))
+        assert np.abs(_np_hist(q_full) - oracle.np_histogram(q_ref)).sum() <= 2 * int((~clear).sum())
+    assert np.array_equal(res.qhist, expect)
+    assert fragile < len(targets)
+    # the same through the one-block-per-frame sort (>= 128 frames per batch) and without per-water q
+    res2 = engine.tet_order_traj(np.repeat(frames, 70, axis=0), np.repeat(boxes, 70, axis=0), ctx=ctx)
+    assert np.array_equal(res2.qhist, 70 * expect)
+    ctx.close()
+
+
+def test_lean_qhist_equals_histogram_of_full_chain_q_config3_box():
+    """three frames of the 100 000-water box: trajectory-mode qhist == np.histogram of the per-frame call's q (full=True:
+    the reference's acos/deg/cos chain); the 4-NN distance histogram == the reference's ceiling(d / w) rule applied to the
+    per-frame call's distances"""
+    import torch
+    from waterorderlib_amd import engine, synth
+    from waterorderlib_amd import water_properties as wp
+    n, T = 100000, 3
+    base, box = synth.lattice_sites(n, seed=2026)
+    rng = np.random.default_rng(7)
+    frames = base[None] + 0.3 * rng.standard_normal((T, n, 3))
+    frames -= box * np.floor(frames / box)
+    boxes = np.tile(box[None], (T, 1))
+    res = engine.tet_order_traj(torch.from_numpy(frames).cuda(), boxes)
+    torch.cuda.synchronize()
+    qh = np.zeros(500, dtype=np.int64)
+    dh = np.zeros(1000, dtype=np.int64)
+    for t in range(T):
+        q, idx, dist, ang = wp.getOrderParamq(frames[t], frames[t], box, full=True)
+        qh += _np_hist(q)
+        k = np.ceil(dist.reshape(-1) / 0.01).astype(np.int64)
+        dh += np.bincount(k[(k >= 1) & (k <= 1000)] - 1, minlength=1000)
+    assert np.array_equal(res.qhist.cpu().numpy(), qh)
+    assert np.array_equal(res.dhist.cpu().numpy(), dh)
+
+
+def test_hbond_decisions_with_the_angle_on_the_cut(oracle):
+    """400 acceptor / donor / hydrogen triples in adjacent-double pairs that straddle the cut-off angle in the reference's
+    arithmetic (host libm acos): dense mask and cell-list form must reproduce every decision"""
+    from waterorderlib_amd import waterlib as wl
+    for angcut in (150.0, 120.0, 133.7):
+        acc, don, hyd, box = edge_cases.hbond_triples_on_the_cut(oracle, n=200, angcut=angcut)
+        ref = oracle.generalhbonds(acc, don, hyd, box, 3.5, angcut)
+        d = np.diag(ref).reshape(-1, 2)
+        assert np.all(d.sum(axis=1) == 1)            # each pair of adjacent doubles straddles the cut
+        got = wl.generalhbonds(acc, don, hyd, box, 3.5, angcut)
+        assert np.array_equal(got, ref)
+        ai, di = wl.generalhbonds_list(acc, don, hyd, box, 3.5, angcut)
+        assert np.array_equal(np.stack([ai, di], axis=1), np.stack(np.where(ref == 1), axis=1))
+
+
+@pytest.mark.parametrize("variant", ["rows512", "rows768", "tiles3d"])
+def test_config2_full_length_on_every_proposal_instantiation(oracle, variant):
+    """BASELINE config 2: 10 000 waters x 1 000 frames, fp64, one MI355X; north-star bar: indices bit-exact, q within
+    1e-6 (asserted at 1e-12).  The proposal kernel's instantiation is forced and read back."""
+    import torch
+    from waterorderlib_amd import _lib, engine, synth
+    from waterorderlib_amd import water_properties as wp
+    n, T = 10000, 1000
+    base, box = synth.lattice_sites(n, seed=404)
+    base = torch.from_numpy(base[np.random.default_rng(2).permutation(n)]).cuda()
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    x = base.unsqueeze(0) + 0.3 * torch.randn((T, n, 3), generator=g, device="cuda", dtype=torch.float64)
+    b = torch.as_tensor(box, device="cuda")
+    frames = (x - b * torch.floor(x / b)).contiguous()
+    boxes = np.tile(box[None], (T, 1))
+    ctx = _lib.Context(0)
+    if variant == "tiles3d":
+        ctx.set_option("search_rows", 0)
+    else:
+        ctx.set_option("rows_block", int(variant[4:]))
+    res = engine.tet_order_traj(frames, boxes, want_q=True, ctx=ctx)
+    torch.cuda.synchronize()
+    assert ctx.counter("rows_block") == {"rows512": 512, "rows768": 768, "tiles3d": 0}[variant]
+    assert ctx.counter("slow_waters") < 0.01 * n * T
+    q = res.q.cpu().numpy()
+    assert int(res.dhist.sum().item()) == 4 * n * T
+    assert int(res.qhist.sum().item()) == int(((q >= 0.0) & (q <= 1.0)).sum())
+    np.testing.assert_allclose(res.mean.cpu().numpy(), q.mean(axis=1), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(res.var.cpu().numpy(), q.var(axis=1), rtol=0, atol=1e-13)
+    oracle.set_threads(8)
+    qh = np.zeros(500, dtype=np.int64)
+    sampled = (0, 211, 499, 500, 777, 999)
+    for t in sampled:
+        pos = frames[t].cpu().numpy()
+        q_o, idx_o, dist_o, ang_o = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+        np.testing.assert_allclose(q[t], q_o, rtol=0, atol=Q_TOL)
+        q_g, idx_g, dist_g, ang_g = wp.getOrderParamq(pos, pos, box, full=True, ctx=ctx)    # same forced instantiation
+        assert ctx.counter("rows_block") == {"rows512": 512, "rows768": 768, "tiles3d": 0}[variant]
+        assert np.array_equal(idx_g, idx_o) and np.array_equal(dist_g, dist_o)
+        np.testing.assert_allclose(ang_g, ang_o, rtol=0, atol=1e-9)
+        qh += oracle.np_histogram(q_o)
+    # the sampled frames on their own: integer histograms bit-exact against the oracle
+    sub = engine.tet_order_traj(frames[list(sampled)].contiguous(), boxes[: len(sampled)], ctx=ctx)
+    assert np.array_equal(sub.qhist.cpu().numpy(), qh)
+    # every variant gives the same integers (kept across the parametrised runs)
+    key = (res.qhist.cpu().numpy().tobytes(), res.dhist.cpu().numpy().tobytes(), res.mean.cpu().numpy().tobytes())
+    prev = test_config2_full_length_on_every_proposal_instantiation.__dict__.setdefault("seen", key)
+    assert prev == key
+    ctx.close()
+
+
+def test_strided_gather_of_the_golden_tip4p_frame():
+    """the O rows are read straight out of the interleaved [O, H, H, EP] frame (TrajObject.getWatInds,
+    TrajObject.py:35-52; `pos[watInds]`, orderParam_lib.py:1462).  tests/golden/ice512_frame.npz is the 2 048-atom frame
+    whose O rows the reference was run on for tests/golden/ice512.npz."""
+    import torch
+    from waterorderlib_amd import TrajObject, engine
+    fr, g = golden("ice512_frame"), golden("ice512")
+    xyz, box, lw = fr["xyz"], fr["box"], int(fr["len_wat"])
+    assert np.array_equal(xyz[0::lw], g["pos"])
+    obj = TrajObject.TrajObject(xyz[None], box[None], lenWat=lw)
+    assert np.array_equal(obj.getWatInds()[0], np.arange(512) * lw)
+    for frames in (xyz[None], torch.from_numpy(xyz[None].copy()).cuda()):
+        res = engine.tet_order_traj(frames, box[None], len_wat=lw, want_q=True)
+        q = res.q.cpu().numpy() if hasattr(res.q, "cpu") else res.q
+        np.testing.assert_allclose(q[0], g["q"], rtol=0, atol=Q_TOL)
+        qh = res.qhist.cpu().numpy() if hasattr(res.qhist, "cpu") else res.qhist
+        assert np.array_equal(qh, _np_hist(g["q"]))
+    # a batch of copies takes the cell-list path's strided reads too (n <= 1024 alone goes through the all-pairs kernel)
+    big = np.tile(xyz[None], (3, 1, 1))
+    from waterorderlib_amd import _lib
+    ctx = _lib.Context(0)
+    ctx.set_option("path", 2)
+    res = engine.tet_order_traj(big, np.tile(box[None], (3, 1)), len_wat=lw, want_q=True, ctx=ctx)
+    for t in range(3):
+        np.testing.assert_allclose(res.q[t], g["q"], rtol=0, atol=Q_TOL)
+    ctx.close()
+
+
+def test_breathing_boxes_reuse_tile_tables(oracle):
+    """an NPT-like trajectory: every frame has its own box; the cell counts -- and with them the memoised tile tables --
+    change a few dozen times (more distinct (cells, waters) keys than the cache holds), boxes repeat later on"""
+    from waterorderlib_amd import _lib, engine, synth
+    n, T = 2500, 60
+    xyz, boxes = synth.water_frames(n, 1, seed=91)
+    rng = np.random.default_rng(91)
+    scale = 1.0 + 0.25 * rng.random((T, 3))
+    scale[40:] = scale[:20]                      # earlier boxes come back
+    frames = xyz[0][None] * scale[:, None, :]
+    bx = boxes[0][None] * scale
+    ctx = _lib.Context(0)
+    ctx.set_option("path", 3)
+    res = engine.tet_order_traj(frames, bx, want_q=True, ctx=ctx)
+    mean, var, qh, dh = oracle.tet_order_traj(frames, bx)
+    assert np.array_equal(res.qhist, qh) and np.array_equal(res.dhist, dh)
+    np.testing.assert_allclose(res.mean, mean, rtol=0, atol=1e-13)
+    for t in (0, 19, 41, 59):
+        np.testing.assert_allclose(res.q[t], oracle.getOrderParamq(frames[t], frames[t], bx[t], cells=True), rtol=0, atol=Q_TOL)
+    ctx.close()

@@ -1,4 +1,5 @@
 """Builds libwol.so (the HIP/C-ABI library) in-tree with hipcc for gfx950."""
+import glob
 import os
 import shutil
 import subprocess
@@ -6,7 +7,6 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwol.so")
-SOURCES = ["wol_api.hip", "wol_kernels.hip", "wol_search_fast.hip", "wol_shell.hip", "wol_device.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 
@@ -14,7 +14,9 @@ def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "..", "include", "wol.h")]
+    # wol_api.hip includes every other file of csrc/: any of them newer than the library means rebuild
+    deps = glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))
+    deps.append(os.path.join(HERE, "..", "include", "wol.h"))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

@@ -106,6 +106,7 @@ struct wol_ctx {
     bool inputs_resident = false;
     size_t sort_rows_lds_set = 0;
     int last_rows_block = 0;
+    int force_rows_block = 0;  // 0 = per batch by lane fill; 512 / 768 = that k_search_rows instantiation (tests, tuning)
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
@@ -130,26 +131,145 @@ Box3 make_box(const double* box) {
     return b;
 }
 
-// Builds the uniform grid of one frame.  Returns false when the frame must take the all-pairs
-// path: a non-periodic axis (BoxL < 0), BoxL == 0 or a non-finite length.
-bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block);
+// Tile tables of the proposal kernels: they depend on the cell counts and the number of waters only, not on the box
+// lengths themselves, so a trajectory whose box breathes (NPT) reuses them from frame to frame; only the scalars
+// (cell widths, key scale, error bounds) are recomputed per frame.
+struct TileTables {
+    int nlev = 0;
+    float lev_wpc[WOL_NLEV];
+    short lev_sx[WOL_NLEV], lev_ry[WOL_NLEV], lev_sz[WOL_NLEV];
+    short lev_ntx[WOL_NLEV], lev_nty[WOL_NLEV], lev_ntz[WOL_NLEV];
+    int lev_ntiles[WOL_NLEV];
+    int ntiles = 0;
+    short row_sx[WOL_NLEV], row_ry[WOL_NLEV], row_ntx[WOL_NLEV], row_nty[WOL_NLEV];
+    int row_ntiles[WOL_NLEV];
+    int row_tiles_max = 0, row_block = WOL_ROWS_BLOCK_A;
+    int max_sx = 1, max_ry = 1, max_sz = 1, rmax_sx = 1, rmax_ry = 1;
+};
 
-// trajectories at constant volume repeat one box: keep the last grid
 // rows_block: k_search_rows instantiation to size the row tiles for (512 or 768); 0 = whichever fills its lanes better
-bool make_grid(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block = 0) {
-    static thread_local struct { double box[3], cw, high; int n, rb; bool ok, valid = false; FrameGrid g; } last;
-    if (last.valid && last.n == n && last.cw == cell_width && last.high == high && last.box[0] == box[0] &&
-        last.box[1] == box[1] && last.box[2] == box[2] && last.rb == rows_block) {
-        *g = last.g;
-        return last.ok;
+void build_tile_tables(const int nc[3], int n, int rows_block, TileTables* t) {
+    const int ncell = nc[0] * nc[1] * nc[2];
+    const double wpc = std::fmax((double)n / (double)ncell, 0.05);
+    // Tile shapes for WOL_NLEV local densities (waters per cell), from the box average upwards; the
+    // device picks the level after the sort (k_pick_level).  A tile = sx x ry x sz cells: as many
+    // waters as fit one sweep of the block (one lane per water) while the halo'd tile ((sz+2) layers
+    // of (ry+2) x (sx+2) cells, each padded to an even count, +15 %) fits the LDS pair buffer and the
+    // row tables; among the fullest shapes the one with the smallest halo.
+    static const double lev_mult[WOL_NLEV] = {1.10, 1.35, 1.75, 2.4, 4.0, 8.0};  // densest tile-sized window / box average
+    t->nlev = WOL_NLEV;
+    t->ntiles = 0;
+    t->max_sx = t->max_ry = t->max_sz = 1;
+    for (int l = 0; l < WOL_NLEV; ++l) {
+        // a level is picked while the densest window stays below lev_wpc; its tiles are sized for the
+        // typical tile of such a frame (the densest windows of a homogeneous liquid sit ~10 % above
+        // the mean; a tile that does get more waters than lanes takes a second sweep)
+        t->lev_wpc[l] = (float)(wpc * lev_mult[l]);
+        const double w = wpc * lev_mult[l] / 1.10;
+        double best = -1.0;
+        int bsx = 1, bry = 1, bsz = 1, bntx = nc[0], bnty = nc[1], bntz = nc[2];
+        for (int sx0 = 1; sx0 <= std::min(nc[0], WOL_FAST_MAXSX); ++sx0) {
+            const int ntx = (nc[0] + sx0 - 1) / sx0, sx = (nc[0] + ntx - 1) / ntx;  // equalised
+            if (sx != sx0) continue;
+            for (int sz0 = 1; sz0 <= std::min(nc[2], WOL_FAST_MAXSZ); ++sz0) {
+                const int ntz = (nc[2] + sz0 - 1) / sz0, sz = (nc[2] + ntz - 1) / ntz;
+                if (sz != sz0) continue;
+                for (int ry0 = 1; ry0 <= std::min(nc[1], WOL_FAST_MAXRY); ++ry0) {
+                    const int nty = (nc[1] + ry0 - 1) / ry0, ry = (nc[1] + nty - 1) / nty;
+                    if (ry != ry0) continue;
+                    if (sz * ry > WOL_FAST_MAXQROWS || (sz + 2) * (ry + 2) > WOL_FAST_MAXROWS) continue;
+                    const double q = sx * ry * sz * w;
+                    const bool unit = (sx == 1 && ry == 1 && sz == 1);
+                    if (q > (double)WOL_FAST_TARGET && !unit) continue;
+                    const double staged = (double)(sz + 2) * (ry + 2) * (sx + 2) * (w + 0.5);
+                    if (staged * 1.15 > 2.0 * WOL_FAST_CAPP && !unit) continue;
+                    // fill of the block's lanes first (5 % bands), then the halo ratio
+                    const double band = std::floor(q / (0.05 * WOL_FAST_TARGET));
+                    const double score = band - staged / (q * 100.0);
+                    if (score > best) { best = score; bsx = sx; bry = ry; bsz = sz; bntx = ntx; bnty = nty; bntz = ntz; }
+                }
+            }
+        }
+        t->lev_sx[l] = (short)bsx; t->lev_ry[l] = (short)bry; t->lev_sz[l] = (short)bsz;
+        t->lev_ntx[l] = (short)bntx; t->lev_nty[l] = (short)bnty; t->lev_ntz[l] = (short)bntz;
+        t->lev_ntiles[l] = bntx * bnty * bntz;
+        t->ntiles = std::max(t->ntiles, t->lev_ntiles[l]);
+        t->max_sx = std::max(t->max_sx, bsx); t->max_ry = std::max(t->max_ry, bry); t->max_sz = std::max(t->max_sz, bsz);
     }
-    const bool ok = make_grid_uncached(box, n, cell_width, high, g, rows_block);
-    last.box[0] = box[0]; last.box[1] = box[1]; last.box[2] = box[2];
-    last.cw = cell_width; last.high = high; last.n = n; last.rb = rows_block; last.ok = ok; last.g = *g; last.valid = true;
-    return ok;
+    // ---- tiles of the row-merged kernel (wol_search_rows.hip): sx cells x ry rows in one z layer;
+    //      staged = (ry + 2) triples of three z rows, sx + 2 cells long ----
+    // the tile search for one instantiation (block threads, capp staged pairs); returns the lane fill at level 0
+    struct RowTiles { short sx[WOL_NLEV], ry[WOL_NLEV], ntx[WOL_NLEV], nty[WOL_NLEV]; double fill0; };
+    auto row_tiles = [&](int block, int capp, RowTiles* rt) {
+        const int target = WOL_ROWS_TARGET(block);
+        for (int l = 0; l < WOL_NLEV; ++l) {
+            const double w = wpc * lev_mult[l] / 1.10;
+            double best = -1.0, bq = 0.0;
+            int bsx = 1, bry = 1, bntx = nc[0], bnty = nc[1];
+            for (int sx0 = 1; sx0 <= std::min(nc[0], WOL_ROWS_MAXSX); ++sx0) {
+                const int ntx = (nc[0] + sx0 - 1) / sx0, sx = (nc[0] + ntx - 1) / ntx;  // equalised
+                if (sx != sx0) continue;
+                for (int ry0 = 1; ry0 <= std::min(nc[1], WOL_ROWS_MAXRY); ++ry0) {
+                    const int nty = (nc[1] + ry0 - 1) / ry0, ry = (nc[1] + nty - 1) / nty;
+                    if (ry != ry0) continue;
+                    const double q = sx * ry * w;
+                    const bool unit = (sx == 1 && ry == 1);
+                    if (q > (double)target && !unit) continue;
+                    const double staged = 3.0 * (ry + 2) * (sx + 2) * w;
+                    if (staged * 1.12 + (ry + 2) > 2.0 * capp && !unit) continue;
+                    if ((ry + 2) * (((sx + 2) * WOL_XSUB + 2) / 2) > WOL_ROWS_BINW) continue;
+                    // fill of the block's lanes first (5 % bands), then the staging ratio
+                    const double band = std::floor(q / (0.05 * target));
+                    const double score = band - staged / (q * 100.0);
+                    if (score > best) { best = score; bsx = sx; bry = ry; bntx = ntx; bnty = nty; bq = q; }
+                }
+            }
+            rt->sx[l] = (short)bsx; rt->ry[l] = (short)bry; rt->ntx[l] = (short)bntx; rt->nty[l] = (short)bnty;
+            if (l == 0) rt->fill0 = bq / (double)block;
+        }
+    };
+    RowTiles rta, rtb;
+    row_tiles(WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A, &rta);
+    row_tiles(WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B, &rtb);
+    // three 512-thread blocks per CU overlap their staging phases better than two of 768: the larger block has to
+    // win clearly on lane fill
+    const int pick = rows_block ? rows_block : (rtb.fill0 > rta.fill0 + 0.06 ? WOL_ROWS_BLOCK_B : WOL_ROWS_BLOCK_A);
+    const RowTiles& rt = pick == WOL_ROWS_BLOCK_B ? rtb : rta;
+    t->row_block = pick;
+    t->row_tiles_max = 0;
+    t->rmax_sx = t->rmax_ry = 1;
+    for (int l = 0; l < WOL_NLEV; ++l) {
+        t->row_sx[l] = rt.sx[l]; t->row_ry[l] = rt.ry[l]; t->row_ntx[l] = rt.ntx[l]; t->row_nty[l] = rt.nty[l];
+        t->row_ntiles[l] = rt.ntx[l] * rt.nty[l] * nc[2];
+        t->row_tiles_max = std::max(t->row_tiles_max, t->row_ntiles[l]);
+        t->rmax_sx = std::max(t->rmax_sx, (int)rt.sx[l]);
+        t->rmax_ry = std::max(t->rmax_ry, (int)rt.ry[l]);
+    }
 }
 
-bool make_grid_uncached(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block) {
+// the tables of (cell counts, waters, requested instantiation), memoised per host thread
+const TileTables& tile_tables(const int nc[3], int n, int rows_block) {
+    struct Entry { int nc[3], n, rb; TileTables t; };
+    static thread_local std::vector<Entry> cache;
+    for (size_t i = 0; i < cache.size(); ++i) {
+        const Entry& e = cache[i];
+        if (e.nc[0] == nc[0] && e.nc[1] == nc[1] && e.nc[2] == nc[2] && e.n == n && e.rb == rows_block) {
+            if (i != 0) std::swap(cache[0], cache[i]);   // most recently used first
+            return cache[0].t;
+        }
+    }
+    if (cache.size() >= 32) cache.pop_back();
+    Entry e;
+    e.nc[0] = nc[0]; e.nc[1] = nc[1]; e.nc[2] = nc[2]; e.n = n; e.rb = rows_block;
+    build_tile_tables(nc, n, rows_block, &e.t);
+    cache.insert(cache.begin(), e);
+    return cache[0].t;
+}
+
+// Builds the uniform grid of one frame.  Returns false when the frame must take the all-pairs
+// path: a non-periodic axis (BoxL < 0), BoxL == 0 or a non-finite length.
+// rows_block: k_search_rows instantiation to size the row tiles for (512 or 768); 0 = whichever fills its lanes better
+bool make_grid(const double* box, int n, double cell_width, double high, FrameGrid* g, int rows_block = 0) {
     g->box = make_box(box);
     g->maxshell = -1;
     g->ncell = 1;
@@ -184,60 +304,28 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
     }
     g->maxshell = ms;
 
-    // ---- tiling for the filtered kernel (wol_search_fast.hip) ----
+    // ---- tiling for the filtered kernels (wol_search_fast.hip, wol_search_rows.hip) ----
     g->fast_ok = 0;
     g->nlev = 0;
     g->ntiles = 0;
     g->scale = 1.f; g->tmax = 0.f; g->S = 1.0; g->eps_units = 0;
     g->row_tiles_max = 0; g->row_eps_units = 0; g->row_block = WOL_ROWS_BLOCK_A;
     if (g->nc[0] >= 3 && g->nc[1] >= 3 && g->nc[2] >= 3) {
+        const TileTables& t = tile_tables(g->nc, n, rows_block);
+        g->nlev = t.nlev;
+        g->ntiles = t.ntiles;
+        g->row_tiles_max = t.row_tiles_max;
+        g->row_block = t.row_block;
+        for (int l = 0; l < WOL_NLEV; ++l) {
+            g->lev_wpc[l] = t.lev_wpc[l];
+            g->lev_sx[l] = t.lev_sx[l]; g->lev_ry[l] = t.lev_ry[l]; g->lev_sz[l] = t.lev_sz[l];
+            g->lev_ntx[l] = t.lev_ntx[l]; g->lev_nty[l] = t.lev_nty[l]; g->lev_ntz[l] = t.lev_ntz[l];
+            g->lev_ntiles[l] = t.lev_ntiles[l];
+            g->row_sx[l] = t.row_sx[l]; g->row_ry[l] = t.row_ry[l]; g->row_ntx[l] = t.row_ntx[l]; g->row_nty[l] = t.row_nty[l];
+            g->row_ntiles[l] = t.row_ntiles[l];
+        }
         const double cwmax = std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double rmax = 1.5 * cwmax + 0.6;            // beyond the largest guaranteed radius
-        const double wpc = std::fmax((double)n / (double)g->ncell, 0.05);
-        // Tile shapes for WOL_NLEV local densities (waters per cell), from the box average upwards; the
-        // device picks the level after the sort (k_pick_level).  A tile = sx x ry x sz cells: as many
-        // waters as fit one sweep of the block (one lane per water) while the halo'd tile ((sz+2) layers
-        // of (ry+2) x (sx+2) cells, each padded to an even count, +15 %) fits the LDS pair buffer and the
-        // row tables; among the fullest shapes the one with the smallest halo.
-        static const double lev_mult[WOL_NLEV] = {1.10, 1.35, 1.75, 2.4, 4.0, 8.0};  // densest tile-sized window / box average
-        g->nlev = WOL_NLEV;
-        int max_sx = 1, max_ry = 1, max_sz = 1;
-        for (int l = 0; l < WOL_NLEV; ++l) {
-            // a level is picked while the densest window stays below lev_wpc; its tiles are sized for the
-            // typical tile of such a frame (the densest windows of a homogeneous liquid sit ~10 % above
-            // the mean; a tile that does get more waters than lanes takes a second sweep)
-            g->lev_wpc[l] = (float)(wpc * lev_mult[l]);
-            const double w = wpc * lev_mult[l] / 1.10;
-            double best = -1.0;
-            int bsx = 1, bry = 1, bsz = 1, bntx = g->nc[0], bnty = g->nc[1], bntz = g->nc[2];
-            for (int sx0 = 1; sx0 <= std::min(g->nc[0], WOL_FAST_MAXSX); ++sx0) {
-                const int ntx = (g->nc[0] + sx0 - 1) / sx0, sx = (g->nc[0] + ntx - 1) / ntx;  // equalised
-                if (sx != sx0) continue;
-                for (int sz0 = 1; sz0 <= std::min(g->nc[2], WOL_FAST_MAXSZ); ++sz0) {
-                    const int ntz = (g->nc[2] + sz0 - 1) / sz0, sz = (g->nc[2] + ntz - 1) / ntz;
-                    if (sz != sz0) continue;
-                    for (int ry0 = 1; ry0 <= std::min(g->nc[1], WOL_FAST_MAXRY); ++ry0) {
-                        const int nty = (g->nc[1] + ry0 - 1) / ry0, ry = (g->nc[1] + nty - 1) / nty;
-                        if (ry != ry0) continue;
-                        if (sz * ry > WOL_FAST_MAXQROWS || (sz + 2) * (ry + 2) > WOL_FAST_MAXROWS) continue;
-                        const double q = sx * ry * sz * w;
-                        const bool unit = (sx == 1 && ry == 1 && sz == 1);
-                        if (q > (double)WOL_FAST_TARGET && !unit) continue;
-                        const double staged = (double)(sz + 2) * (ry + 2) * (sx + 2) * (w + 0.5);
-                        if (staged * 1.15 > 2.0 * WOL_FAST_CAPP && !unit) continue;
-                        // fill of the block's lanes first (5 % bands), then the halo ratio
-                        const double band = std::floor(q / (0.05 * WOL_FAST_TARGET));
-                        const double score = band - staged / (q * 100.0);
-                        if (score > best) { best = score; bsx = sx; bry = ry; bsz = sz; bntx = ntx; bnty = nty; bntz = ntz; }
-                    }
-                }
-            }
-            g->lev_sx[l] = (short)bsx; g->lev_ry[l] = (short)bry; g->lev_sz[l] = (short)bsz;
-            g->lev_ntx[l] = (short)bntx; g->lev_nty[l] = (short)bnty; g->lev_ntz[l] = (short)bntz;
-            g->lev_ntiles[l] = bntx * bnty * bntz;
-            g->ntiles = std::max(g->ntiles, g->lev_ntiles[l]);
-            max_sx = std::max(max_sx, bsx); max_ry = std::max(max_ry, bry); max_sz = std::max(max_sz, bsz);
-        }
         const double kunits = std::ldexp(1.0, 32 - WOL_ID_BITS);
         g->S = kunits / (rmax * rmax);                      // key units over [0, rmax^2)
         g->scale = (float)std::sqrt(g->S);
@@ -247,7 +335,7 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
         // magnitude M), differences of two such numbers are exact, the three fmas round to integers
         // (staged coordinates are cell-local values plus a cell offset, centred on the tile: M is half
         // the halo'd tile extent)
-        const double ext = std::fmax(0.5 * (max_sx + 2) * g->cw[0], std::fmax(0.5 * (max_ry + 2) * g->cw[1], 0.5 * (max_sz + 2) * g->cw[2]))
+        const double ext = std::fmax(0.5 * (t.max_sx + 2) * g->cw[0], std::fmax(0.5 * (t.max_ry + 2) * g->cw[1], 0.5 * (t.max_sz + 2) * g->cw[2]))
                            + std::fmax(g->cw[0], std::fmax(g->cw[1], g->cw[2]));
         const double M = ext * g->scale;
         const double ulpM = std::ldexp(1.0, (int)std::ceil(std::log2(M)) - 24);
@@ -255,65 +343,15 @@ bool make_grid_uncached(const double* box, int n, double cell_width, double high
         const double eps = 2.0 * 1.7320508 * (rmax * g->scale) * (2.0 * ulpM) + 1.5;
         g->eps_units = (int)std::ceil(eps * 1.25) + 2;
         g->fast_ok = (high >= rmax) ? 1 : 0;
-
-        // ---- tiles of the row-merged kernel (wol_search_rows.hip): sx cells x ry rows in one z layer;
-        //      staged = (ry + 2) triples of three z rows, sx + 2 cells long ----
-        // the tile search for one instantiation (block threads, capp staged pairs); returns the lane fill at level 0
-        struct RowTiles { short sx[WOL_NLEV], ry[WOL_NLEV], ntx[WOL_NLEV], nty[WOL_NLEV]; double fill0; };
-        auto row_tiles = [&](int block, int capp, RowTiles* rt) {
-            const int target = WOL_ROWS_TARGET(block);
-            for (int l = 0; l < WOL_NLEV; ++l) {
-                const double w = wpc * lev_mult[l] / 1.10;
-                double best = -1.0, bq = 0.0;
-                int bsx = 1, bry = 1, bntx = g->nc[0], bnty = g->nc[1];
-                for (int sx0 = 1; sx0 <= std::min(g->nc[0], WOL_ROWS_MAXSX); ++sx0) {
-                    const int ntx = (g->nc[0] + sx0 - 1) / sx0, sx = (g->nc[0] + ntx - 1) / ntx;  // equalised
-                    if (sx != sx0) continue;
-                    for (int ry0 = 1; ry0 <= std::min(g->nc[1], WOL_ROWS_MAXRY); ++ry0) {
-                        const int nty = (g->nc[1] + ry0 - 1) / ry0, ry = (g->nc[1] + nty - 1) / nty;
-                        if (ry != ry0) continue;
-                        const double q = sx * ry * w;
-                        const bool unit = (sx == 1 && ry == 1);
-                        if (q > (double)target && !unit) continue;
-                        const double staged = 3.0 * (ry + 2) * (sx + 2) * w;
-                        if (staged * 1.12 + (ry + 2) > 2.0 * capp && !unit) continue;
-                        if ((ry + 2) * (((sx + 2) * WOL_XSUB + 2) / 2) > WOL_ROWS_BINW) continue;
-                        // fill of the block's lanes first (5 % bands), then the staging ratio
-                        const double band = std::floor(q / (0.05 * target));
-                        const double score = band - staged / (q * 100.0);
-                        if (score > best) { best = score; bsx = sx; bry = ry; bntx = ntx; bnty = nty; bq = q; }
-                    }
-                }
-                rt->sx[l] = (short)bsx; rt->ry[l] = (short)bry; rt->ntx[l] = (short)bntx; rt->nty[l] = (short)bnty;
-                if (l == 0) rt->fill0 = bq / (double)block;
-            }
-        };
-        RowTiles rta, rtb;
-        row_tiles(WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A, &rta);
-        row_tiles(WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B, &rtb);
-        // three 512-thread blocks per CU overlap their staging phases better than two of 768: the larger block has to
-        // win clearly on lane fill
-        const int pick = rows_block ? rows_block : (rtb.fill0 > rta.fill0 + 0.06 ? WOL_ROWS_BLOCK_B : WOL_ROWS_BLOCK_A);
-        const RowTiles& rt = pick == WOL_ROWS_BLOCK_B ? rtb : rta;
-        g->row_block = pick;
-        g->row_tiles_max = 0;
-        int rmax_sx = 1, rmax_ry = 1;
-        for (int l = 0; l < WOL_NLEV; ++l) {
-            g->row_sx[l] = rt.sx[l]; g->row_ry[l] = rt.ry[l]; g->row_ntx[l] = rt.ntx[l]; g->row_nty[l] = rt.nty[l];
-            g->row_ntiles[l] = rt.ntx[l] * rt.nty[l] * g->nc[2];
-            g->row_tiles_max = std::max(g->row_tiles_max, g->row_ntiles[l]);
-            rmax_sx = std::max(rmax_sx, (int)rt.sx[l]);
-            rmax_ry = std::max(rmax_ry, (int)rt.ry[l]);
-        }
         {
             // per-axis coordinate magnitudes: x up to half the staged tile length, y half the staged rows
             // (both + one cell-local value), z one and a half cells; errors add in quadrature over the axes
-            auto ulp_of = [&](double ext) {
-                const double Mk = ext * g->scale;
+            auto ulp_of = [&](double ext_) {
+                const double Mk = ext_ * g->scale;
                 return std::ldexp(1.0, (int)std::ceil(std::log2(Mk)) - 24);
             };
-            const double ux = ulp_of(0.5 * (rmax_sx + 2) * g->cw[0] + g->cw[0]);
-            const double uy = ulp_of(0.5 * (rmax_ry + 2) * g->cw[1] + g->cw[1]);
+            const double ux = ulp_of(0.5 * (t.rmax_sx + 2) * g->cw[0] + g->cw[0]);
+            const double uy = ulp_of(0.5 * (t.rmax_ry + 2) * g->cw[1] + g->cw[1]);
             const double uz = ulp_of(2.0 * g->cw[2]);
             // |key - exact d2| <= 2 d (2 |ulp|) + 1.5 in key units (d in sqrt(key units)), padded by 25 % + 2: a slope and
             // an offset for the kernel's near-tie test at the distance in question, the value at rmax for everything else
@@ -406,7 +444,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     int n_cell_frames = 0;
     std::vector<int> brute_frames;
     const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
-    int rows_block = 0;   // the k_search_rows instantiation of this batch: the first frame's choice
+    int rows_block = c->force_rows_block;   // the k_search_rows instantiation of this batch: forced, or the first frame's choice
     for (int f = 0; f < F; ++f) {
         bool ok = !force_brute && make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f], rows_block);
         if (ok && rows_block == 0) rows_block = gh[f].row_block;
@@ -493,7 +531,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             P = std::min(P, std::max(1, n / (4 * WOL_SORT_BLOCK)));                  // at least a few chunks each
             if (P == 1 && big_rows) P = 2;                                           // the fused kernel's tables end at MAXROWS
         }
-        if (layer_sort && c->sort_parts > 0) P = c->sort_parts;                      // tuning override
+        if (layer_sort && c->sort_parts > 0) P = std::max(c->sort_parts, big_rows ? 2 : 1);   // tuning override (big row tables need the split form)
         if (layer_sort) {
             const int ro_stride = nrow_max + 1;
             WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
@@ -928,6 +966,11 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->inputs_resident = value != 0.0;
     } else if (k == "search_rows") {
         c->search_rows = value != 0.0;
+    } else if (k == "rows_block") {
+        const int v = (int)value;
+        if (v != 0 && v != WOL_ROWS_BLOCK_A && v != WOL_ROWS_BLOCK_B)
+            return fail(WOL_ERR_INVALID, "rows_block must be 0, %d or %d", WOL_ROWS_BLOCK_A, WOL_ROWS_BLOCK_B);
+        c->force_rows_block = v;
     } else if (k == "sort_parts") {
         c->sort_parts = (int)value;
     } else if (k == "search_margin") {
@@ -1399,6 +1442,53 @@ int wol_pair_distance_histogram(wol_ctx* c, const double* pos1, int n1, const do
 }
 
 // ---- hydrogen bonds --------------------------------------------------------------
+// the cut-off angle with cos / sin of its radian value as double-doubles (~106 bits), for the device's exact decision
+// next to the cut (wol_ang_below_cut).  Minimal double-double arithmetic (error-free sums and fma products) and the
+// Taylor series of sin / cos about pi/2.
+namespace ddm {
+struct dd { double hi, lo; };
+inline dd two_sum(double a, double b) { const double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)}; }
+inline dd quick(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+inline dd add(dd a, dd b) { dd s = two_sum(a.hi, b.hi); s.lo += a.lo + b.lo; return quick(s.hi, s.lo); }
+inline dd neg(dd a) { return {-a.hi, -a.lo}; }
+inline dd mul(dd a, dd b) {
+    const double p = a.hi * b.hi, e = std::fma(a.hi, b.hi, -p) + (a.hi * b.lo + a.lo * b.hi);
+    return quick(p, e);
+}
+inline dd div_d(dd a, double b) {   // a / b, b a small integer
+    const double q1 = a.hi / b;
+    const double r = std::fma(-q1, b, a.hi) + a.lo;
+    return quick(q1, r / b);
+}
+// sin and cos of x, |x| <= pi/2, Taylor series to x^41 (remainder below 1e-33)
+inline void sin_cos(dd x, dd* sn, dd* cs) {
+    const dd x2 = mul(x, x);
+    dd ts = x, tc = {1.0, 0.0}, s = x, c = {1.0, 0.0};
+    for (int k = 1; k <= 20; ++k) {
+        tc = neg(div_d(mul(tc, x2), (double)((2 * k - 1) * (2 * k))));
+        ts = neg(div_d(mul(ts, x2), (double)((2 * k) * (2 * k + 1))));
+        c = add(c, tc);
+        s = add(s, ts);
+    }
+    *sn = s; *cs = c;
+}
+}  // namespace ddm
+
+static AngCut make_ang_cut(double angcut) {
+    AngCut k;
+    k.cut_deg = angcut;
+    k.A = angcut * (WOL_PI / 180.0);
+    k.refine = (angcut >= 1.0 && angcut <= 179.0) ? 1 : 0;
+    // A = pi/2 + x: cos A = -sin x, sin A = cos x
+    const ddm::dd half_pi = {1.5707963267948966, 6.123233995736766e-17};
+    const ddm::dd x = ddm::add(ddm::dd{k.A, 0.0}, ddm::neg(half_pi));
+    ddm::dd sn, cs;
+    ddm::sin_cos(x, &sn, &cs);
+    k.cA_hi = -sn.hi; k.cA_lo = -sn.lo;
+    k.sA = cs.hi;
+    return k;
+}
+
 int wol_general_hbonds(wol_ctx* c, const double* acc, int nacc, const double* don, const double* donh, int ndon,
                        const double* box, double distcut, double angcut, int32_t* bond) {
     WOL_TRY(check_ctx(c));
@@ -1416,7 +1506,7 @@ int wol_general_hbonds(wol_ctx* c, const double* acc, int nacc, const double* do
     HIP_TRY(hipMemcpyAsync(d_d, don, db, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(d_h, donh, db, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_hbonds_dense, dim3((unsigned)((total + WOL_BLOCK - 1) / WOL_BLOCK)), dim3(WOL_BLOCK), 0, c->stream,
-                       d_a, nacc, d_d, d_h, ndon, make_box(box), distcut * distcut, angcut, c->out_stage.as<int32_t>());
+                       d_a, nacc, d_d, d_h, ndon, make_box(box), distcut * distcut, make_ang_cut(angcut), c->out_stage.as<int32_t>());
     HIP_TRY(hipMemcpyAsync(bond, c->out_stage.p, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
@@ -1440,7 +1530,7 @@ int wol_general_hbonds_list(wol_ctx* c, const double* acc, int nacc, const doubl
     HIP_TRY(hipMemcpyAsync(c->out_stage.p, donh, sizeof(double) * 3 * (size_t)ndon, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->small.p, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_hbonds_list, dim3((nacc + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream, sa,
-                       c->out_stage.as<double>(), distcut * distcut, angcut, c->slow_list.as<unsigned long long>(),
+                       c->out_stage.as<double>(), distcut * distcut, make_ang_cut(angcut), c->slow_list.as<unsigned long long>(),
                        (unsigned long long)capacity, c->small.as<unsigned long long>());
     unsigned long long found = 0;
     HIP_TRY(hipMemcpyAsync(&found, c->small.p, sizeof found, hipMemcpyDeviceToHost, c->stream));

@@ -1058,14 +1058,40 @@ __global__ void k_lsi_dists(const double* __restrict__ neigh, int n, double r0, 
 // water orientation (waterlib.f90:954-1044: AngBetween, watOrient, watOHvec).
 // One lane per water: 72 B in (O, H1, H2), 16 B (two angles) or 24 B (unit dipole) out -- HBM-bound streaming.
 // =============================================================================================
-__device__ __forceinline__ double wol_ang_between(const double a[3], const double b[3]) {
+// AngBetween (waterlib.f90:954-965) behind its acos: the wrap into (-pi, pi] and the conversion to degrees
+__device__ __forceinline__ double wol_ang_wrap_deg(double phi) {
     const double pi = WOL_PI;
     const double DegPerRad = 180.0 / pi;
-    double phi = fmin(1.0, fmax(-1.0, (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]));
-    phi = acos(phi);
     double r = fmod(phi + pi, pi * 2.0) - pi;
     if (r < -pi) r = r + pi * 2.0;
     return r * DegPerRad;
+}
+
+__device__ __forceinline__ double wol_ang_between(const double a[3], const double b[3]) {
+    const double phi = fmin(1.0, fmax(-1.0, (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]));
+    return wol_ang_wrap_deg(acos(phi));
+}
+
+// A cut-off angle prepared on the host for exact decisions `AngBetween(...) < angCut` (generalHbonds,
+// waterlib.f90:1200): A = the cut in radians as a double, cos A as a double-double, sin A.  The device's acos may
+// differ from the host libm's in the last place; within 1e-9 degrees of the cut the CORRECTLY ROUNDED acos is formed
+// instead, from the expansion of acos about A (cos(A + e) = phi  =>  e = (cos A - phi)/sin A - (cos A / 2 sin A) e^2,
+// |e| < 2e-11: the next term is below 1e-33), and the reference's own chain (wrap, degrees, compare) is applied to it.
+struct AngCut {
+    double cut_deg;
+    double A, cA_hi, cA_lo, sA;
+    int refine;     // 0: the cut is too close to 0 or 180 degrees for the expansion (sin A ~ 0); device acos decides
+};
+
+__device__ __forceinline__ bool wol_ang_below_cut(const double a[3], const double b[3], const AngCut& k) {
+    const double phi = fmin(1.0, fmax(-1.0, (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]));
+    double ang = wol_ang_wrap_deg(acos(phi));
+    if (k.refine && fabs(ang - k.cut_deg) < 1e-9) {
+        const double e1 = ((k.cA_hi - phi) + k.cA_lo) / k.sA;            // cA_hi - phi is exact (Sterbenz)
+        const double e = e1 - (k.cA_hi / (2.0 * k.sA)) * (e1 * e1);
+        ang = wol_ang_wrap_deg(k.A + e);                                 // one rounding: the correctly rounded acos(phi)
+    }
+    return ang < k.cut_deg;
 }
 
 __device__ __forceinline__ void wol_oh_vectors(const double* __restrict__ opos, const double* __restrict__ hpos, int i,

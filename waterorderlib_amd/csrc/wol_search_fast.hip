@@ -588,6 +588,9 @@ k_finish_fast(FastArgs a) {
             int dbin[4];
             double dmax = 0.0;
             bool all_in = true;
+            // |d - ((c + d) - c)| per component: two roundings at the magnitude of the coordinates (which may be
+            // unwrapped, i.e. far larger than the box); the bin-edge guards below widen with it
+            const double cguard = 1e-14 * (fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2]))) + a.high);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 // waterlib.f90:733-735 with rint for anint: they differ only on exact half-integers, i.e. a neighbour
@@ -606,7 +609,7 @@ k_finish_fast(FastArgs a) {
                 // on an integer, the reference's distance and the true division decide
                 const double tq = dist * dinv;
                 double cb = ceil(tq);
-                if (fabs(tq - rint(tq)) < 1e-9 * tq) {
+                if (fabs(tq - rint(tq)) < 1e-9 * tq + cguard * dinv) {
                     const double vx = (c[0] + dx) - c[0], vy = (c[1] + dy) - c[1], vz = (c[2] + dz) - c[2];
                     cb = ceil(sqrt(wol_sumsq(vx, vy, vz)) / a.out.dbinwidth);
                 }
@@ -649,21 +652,31 @@ k_finish_fast(FastArgs a) {
 #pragma unroll
                 for (int m = 0; m < 6; ++m) ssum += tm[m];
                 const double q = 1.0 - (3.0 / 8.0) * ssum;
-                if (a.out.q || a.out.q32) {
-                    const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
-                    if (a.out.q) a.out.q[orow] = q;
-                    if (a.out.q32) a.out.q32[orow] = (float)q;
-                }
-                wol_fix_split_fast(q, &acc_h, &acc_l);
-                wol_fix_split_fast(q * q, &acc_h2, &acc_l2);
-                if (lds_qh) {
-                    const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
-                    if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
-                }
-                if (lds_dh) {
+                // This q is within 2e-14 of the reference's acos -> degrees -> cos chain (wp:376-388), which is what
+                // np.histogram bins (opl:1493).  Where that could matter -- q within 1e-8 of a bin width from a bin edge
+                // (0 and 1 included) -- the water goes to the exact kernel, which evaluates the reference's chain in
+                // exact rank order: the integer histogram is the reference's by construction.
+                const double tq_ = q * (double)a.out.qbins;
+                if (lds_qh && fabs(tq_ - rint(tq_)) < 1e-8 + cguard * (double)a.out.qbins && tq_ > -0.5 &&
+                    tq_ < (double)a.out.qbins + 0.5) {
+                    slow = true;
+                } else {
+                    if (a.out.q || a.out.q32) {
+                        const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
+                        if (a.out.q) a.out.q[orow] = q;
+                        if (a.out.q32) a.out.q32[orow] = (float)q;
+                    }
+                    wol_fix_split_fast(q, &acc_h, &acc_l);
+                    wol_fix_split_fast(q * q, &acc_h2, &acc_l2);
+                    if (lds_qh) {
+                        const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
+                        if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
+                    }
+                    if (lds_dh) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (dbin[k] >= 0) atomicAdd(&lds_dh[dbin[k]], 1);
+                        for (int k = 0; k < 4; ++k)
+                            if (dbin[k] >= 0) atomicAdd(&lds_dh[dbin[k]], 1);
+                    }
                 }
             }
         } } else if (live && !slow) {
@@ -704,7 +717,8 @@ k_finish_fast(FastArgs a) {
                     N[k][0] = m.x; N[k][1] = m.y; N[k][2] = m.z;
                 }
                 const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
-                if (a.fast_q) wol_finish_water_fastq(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, f, lds_qh, lds_dh);
+                // (q straight from the cosines only where no histogram is binned from it: bins are the full chain's)
+                if (a.fast_q && !lds_qh) wol_finish_water_fastq(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, f, lds_qh, lds_dh);
                 else wol_finish_water(c, t, N[0], N[1], N[2], N[3], g.box, a.out, orow, f, lds_qh, lds_dh);
             }
         }

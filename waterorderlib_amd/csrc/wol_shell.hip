@@ -350,7 +350,7 @@ k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long l
 // list through the cell list on the donors (reach distCut), for frames where the mask would not fit.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wol_hbond_pair(const double a[3], const double d[3], const double* __restrict__ h,
-                                               const Box3& b, double distcutsq, double angcut) {
+                                               const Box3& b, double distcutsq, const AngCut& angcut) {
     double av[3], dv[3];
     const double v0 = wol_minimg1(d[0] - a[0], b.L[0], b.ib[0]), v1 = wol_minimg1(d[1] - a[1], b.L[1], b.ib[1]);
     const double v2 = wol_minimg1(d[2] - a[2], b.L[2], b.ib[2]);
@@ -364,12 +364,12 @@ __device__ __forceinline__ bool wol_hbond_pair(const double a[3], const double d
     const double na = sqrt(wol_sumsq(av[0], av[1], av[2])), nd = sqrt(wol_sumsq(dv[0], dv[1], dv[2]));
 #pragma unroll
     for (int k = 0; k < 3; ++k) { av[k] = av[k] / na; dv[k] = dv[k] / nd; }
-    return !(wol_ang_between(av, dv) < angcut);
+    return !wol_ang_below_cut(av, dv, angcut);   // waterlib.f90:1200: `if (ang < angCut) cycle`
 }
 
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_hbonds_dense(const double* __restrict__ acc, int nacc, const double* __restrict__ don, const double* __restrict__ donh,
-               int ndon, Box3 b, double distcutsq, double angcut, int32_t* __restrict__ bond) {
+               int ndon, Box3 b, double distcutsq, AngCut angcut, int32_t* __restrict__ bond) {
     const int64_t e = (int64_t)blockIdx.x * WOL_BLOCK + threadIdx.x;   // element of the (nacc, ndon) Fortran-order mask
     if (e >= (int64_t)nacc * ndon) return;
     const int j = (int)(e / nacc), i = (int)(e - (int64_t)j * nacc);
@@ -380,7 +380,7 @@ k_hbonds_dense(const double* __restrict__ acc, int nacc, const double* __restric
 
 // sparse form: a.sorted = cell-sorted donors, a.sub = acceptors; pairs appended as (acceptor << 32 | donor)
 __global__ void __launch_bounds__(WOL_BLOCK)
-k_hbonds_list(ShellArgs a, const double* __restrict__ donh, double distcutsq, double angcut,
+k_hbonds_list(ShellArgs a, const double* __restrict__ donh, double distcutsq, AngCut angcut,
               unsigned long long* __restrict__ pairs, unsigned long long capacity, unsigned long long* __restrict__ count) {
     const int q = blockIdx.x * WOL_BLOCK + threadIdx.x;
     if (q >= a.ns) return;

@@ -46,10 +46,7 @@ def tet_order_traj(frames, boxes, lowCut=0.0, highCut=10.0, len_wat=1, qbins=QBI
     if frames.ndim != 3 or frames.shape[2] != 3:
         raise ValueError("frames must have shape (T, natoms, 3)")
     T, natoms, _ = frames.shape
-    if len(boxes) != T:
-        raise ValueError("boxes must have one row per frame")
-    if natoms % len_wat:
-        raise ValueError("natoms is not a multiple of len_wat")
+    _check_shapes(T, natoms, boxes, len_wat)
     n = natoms // len_wat
     ctx = ctx or _lib.default_context()
     mean = np.zeros(T); var = np.zeros(T)
@@ -65,6 +62,14 @@ def tet_order_traj(frames, boxes, lowCut=0.0, highCut=10.0, len_wat=1, qbins=QBI
     return TrajResult(mean, var, qh, dh, q)
 
 
+def _check_shapes(T, natoms, boxes, len_wat):
+    # the library reads boxes[3*f] for every frame and waters at multiples of len_wat: both must cover the frames
+    if len(boxes) != T:
+        raise ValueError("boxes must have one row per frame")
+    if len_wat < 1 or natoms % len_wat:
+        raise ValueError("natoms is not a multiple of len_wat")
+
+
 def _traj_device(frames, boxes, lowCut, highCut, len_wat, qbins, dbins, dbinwidth, want_q, want_dhist, ctx):
     import torch
     if not frames.is_cuda:
@@ -73,6 +78,7 @@ def _traj_device(frames, boxes, lowCut, highCut, len_wat, qbins, dbins, dbinwidt
         raise ValueError("frames must be a float64/float32 tensor of shape (T, natoms, 3)")
     frames = frames.contiguous()
     T, natoms, _ = frames.shape
+    _check_shapes(T, natoms, boxes, len_wat)
     n = natoms // len_wat
     dev = frames.device
     ctx = ctx or _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
