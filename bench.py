@@ -12,9 +12,13 @@ collective) and the job ends with the path's single exchange step, an RCCL all-r
 histograms + all-gather of the per-frame (mean, var) series, inside the timed region.
 
 Rank 0 prints ONE JSON line; `value` is whole-job frames/s.  `roofline` prices the dominant
-kernel against HBM using ALGORITHMIC bytes (32 B per water: 24 B of O coordinates in, 8 B of q out;
-DESIGN.md) over its HIP-event-measured launch time; `cpu_baseline` is the CPU oracle (a port of
-the reference's algorithm) timed on this host on a bounded sample of the same workload.
+kernel against HBM using ALGORITHMIC bytes (24 B of O coordinates per water in; + 8 B of q out when
+per-water q is written, --want-q) over its HIP-event-measured launch time, and carries the
+kernel's real limiter as `secondary` (VALU issue: instructions per water from the committed rocprofv3
+counter pass over this same command, priced at 4 cycles per wave64 instruction on 1024 SIMDs);
+`end_to_end` is the same workload fed from HOST memory (TIP4P-interleaved frames, double-buffered
+over PCIe) -- never `value`; `cpu_baseline` is the CPU oracle (a port of the reference's algorithm)
+timed on this host on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -27,8 +31,13 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_BYTES_PER_WATER = {"f64": 32.0, "f32": 16.0}
-HBM_PEAK_GBPS = 8000.0                            # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALG_BYTES_IN = {"f64": 24.0, "f32": 12.0}     # O coordinates read per water ...
+ALG_BYTES_Q = {"f64": 8.0, "f32": 4.0}        # ... and q written per water (only when the caller asks for per-water q)
+HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: 8.0 TB/s spec
+N_SIMD = 1024                                 # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9                         # MI355X_MICROARCH.md: max clock
+VALU_ISSUE_CYCLES = 4                         # cycles one wave64 VALU instruction holds its SIMD (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, profiles/)
+COUNTERS_FILE = os.path.join("profiles", "r02_sq_counters.json")
 
 
 def make_frames(torch, base_dev, box, n_frames, seed, sigma, dtype):
@@ -70,6 +79,40 @@ def cpu_baseline(pos_host, box, sample_waters, threads):
     }
 
 
+def end_to_end(torch, engine, ctx, batch_dev, box, args):
+    """The same workload fed from HOST memory, as the reference's caller holds it (orderParam_lib.py:1458-1462):
+    TIP4P-interleaved frames [O, H, H, EP] in a numpy array (pageable) and in pinned memory, through wol_q_traj's
+    WOL_MEM_HOST path (double-buffered staging, the copy of one batch under the kernels of the previous one).
+    The link carries the whole interleaved frames (tools/pcie_probe.hip: 24-byte strided copies are no faster), so the
+    bound is PCIe bytes per second / bytes per frame AS LAID OUT IN HOST MEMORY."""
+    F0, n, _ = batch_dev.shape
+    T = max(F0, args.e2e_frames)
+    lw = 4
+    o = batch_dev.cpu()
+    host = torch.zeros((T, n * lw, 3), dtype=o.dtype).pin_memory()
+    for t in range(T):
+        host[t, 0::lw] = o[t % F0]
+    boxes = np.tile(box[None, :], (T, 1))
+    out = {"frames": T, "atoms_per_water": lw, "frame_bytes": int(host[0].numel() * host.element_size())}
+    for name, arr in (("pinned", host.numpy()), ("pageable", host.numpy().copy())):
+        engine.tet_order_traj(arr[:64], boxes[:64], len_wat=lw, ctx=ctx)          # warm: staging buffers, page faults
+        t0 = time.perf_counter()
+        res = engine.tet_order_traj(arr, boxes, len_wat=lw, ctx=ctx)
+        dt = time.perf_counter() - t0
+        moved = ctx.counter("h2d_bytes")
+        out[name] = {"frames_per_s": T / dt, "GBps_pcie": moved / dt / 1e9, "ms": 1e3 * dt,
+                     "bound_frames_per_s_at_this_rate": (moved / dt) / out["frame_bytes"],
+                     "mean_q": float(np.mean(res.mean))}
+    # O-only host frames (what a caller that slices the oxygens out first would hand over): 4x fewer bytes per frame
+    oo = o[:F0].repeat((T + F0 - 1) // F0, 1, 1)[:T].contiguous().pin_memory().numpy()
+    engine.tet_order_traj(oo[:64], boxes[:64], ctx=ctx)
+    t0 = time.perf_counter()
+    engine.tet_order_traj(oo, boxes, ctx=ctx)
+    dt = time.perf_counter() - t0
+    out["o_only_pinned"] = {"frames_per_s": T / dt, "GBps_pcie": ctx.counter("h2d_bytes") / dt / 1e9, "frame_bytes": int(oo[0].nbytes)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +132,11 @@ def main():
     ap.add_argument("--search-margin", type=int, default=-1, help="blocks per CU the proposal kernel leaves free")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run "
-                         "(default: profiles/r01_hbm_traffic_pmc.json when the workload matches it)")
+                         "(default: the committed counter pass, %s, when the workload matches it)" % COUNTERS_FILE)
+    ap.add_argument("--want-q", action="store_true", help="also write per-water q (8 B per water more per step)")
+    ap.add_argument("--rows-block", type=int, default=-1, help="force the proposal kernel's instantiation (512 / 768)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory (PCIe-inclusive) leg")
+    ap.add_argument("--e2e-frames", type=int, default=192, help="host frames of the end-to-end leg")
     args = ap.parse_args()
 
     import torch
@@ -105,8 +152,9 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch N ranks with torch.distributed.run for --gpus N)"
+                         % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -136,6 +184,8 @@ def main():
         ctx.set_option("sort_parts", args.sort_parts)
     if args.search_margin >= 0:
         ctx.set_option("search_margin", args.search_margin)
+    if args.rows_block >= 0:
+        ctx.set_option("rows_block", args.rows_block)
 
     total_steps = args.warmup + args.steps
     # every step owns its frames; generated (untimed) up front so the timed region only reads HBM
@@ -143,7 +193,9 @@ def main():
     torch.cuda.synchronize()
 
     def step(s):
-        return engine.tet_order_traj(batches[s], boxes, want_q=False, want_dhist=True, ctx=ctx)
+        return engine.tet_order_traj(batches[s], boxes, want_q=args.want_q, want_dhist=True, ctx=ctx)
+
+    exchange_ms = [0.0]
 
     def run_job(first, count):
         """`count` steps starting at batch `first`, then the job-level reduction: sum of the per-step
@@ -154,7 +206,15 @@ def main():
         mean = torch.cat([r.mean for r in results])
         var = torch.cat([r.var for r in results])
         local = engine.TrajResult(mean, var, qh, dh)
-        return engine.reduce_traj_result(local, world * count * F) if distributed else local
+        if not distributed:
+            return local
+        torch.cuda.synchronize()      # so the exchange step can be timed on its own (diagnostic; inside the timed region)
+        local_done = time.perf_counter()
+        out = engine.reduce_traj_result(local, world * count * F)
+        torch.cuda.synchronize()
+        exchange_ms[0] = 1e3 * (time.perf_counter() - local_done)
+        run_job.local_s = local_done
+        return out
 
     if args.warmup > 0:
         run_job(0, args.warmup)  # untimed: also loads every kernel the timed region uses
@@ -166,38 +226,59 @@ def main():
     t0 = time.perf_counter()
     total = run_job(args.warmup, args.steps)
     torch.cuda.synchronize()
+    t_local = (getattr(run_job, "local_s", None) or time.perf_counter()) - t0   # this rank's own frames, before the exchange
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = torch.tensor([args.steps * F / t_local, exchange_ms[0]], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"frames_per_s_before_exchange": [float(a[0].item()) for a in allr],
+                    "exchange_step_ms": [float(a[1].item()) for a in allr]}
     k_ms, k_launches = ctx.kernel_time(reset=False)
     slow_last = ctx.counter("slow_waters")
     dens_level = ctx.counter("density_level")
     rows_block = ctx.counter("rows_block")
 
     if rank == 0:
-        traffic = args.traffic_bytes
-        if traffic is None:
-            # counters cannot be collected inside this run (rocprofv3 --pmc is its own pass); use the
-            # committed PMC result when this run is the workload it was measured on
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
-                cfg = tj["config"]
-                if cfg["waters"] == n and cfg["frames_per_step"] == F and cfg["dtype"] == args.dtype:
-                    traffic = tj["k_search_rows_hbm_bytes_per_launch"]
-            except (OSError, KeyError, ValueError):
-                traffic = None
+        kname = "k_search_rows" if args.search_rows != 0 else "k_search_fast"
+        # counters cannot be collected inside this run (rocprofv3 --pmc is its own pass, tools/collect_sq_counters.sh);
+        # the committed pass over this same command supplies HBM traffic and instruction counts when the workload matches
+        traffic, traffic_source, insts = args.traffic_bytes, ("--traffic-bytes" if args.traffic_bytes else None), None
+        try:
+            tj = json.load(open(os.path.join(ROOT, COUNTERS_FILE)))
+            cfg = tj.get("_config", {})
+            if cfg.get("waters") == n and cfg.get("frames_per_step") == F and cfg.get("dtype") == args.dtype:
+                ent = next(v for k, v in tj.items() if k.startswith(kname))
+                cnt = ent["counters_per_dispatch"]
+                insts = cnt.get("SQ_INSTS_VALU")
+                if traffic is None and "FETCH_SIZE" in cnt and "WRITE_SIZE" in cnt:
+                    # KiB per dispatch; FETCH_SIZE counts half the bytes of 16-B-per-lane loads on gfx950 (guide, HBM section)
+                    traffic = 1024.0 * (2.0 * cnt["FETCH_SIZE"] + cnt["WRITE_SIZE"])
+                    traffic_source = COUNTERS_FILE + " (separate rocprofv3 --pmc passes, FETCH_SIZE doubled)"
+        except (OSError, KeyError, ValueError, StopIteration):
+            pass
         frames_total = world * args.steps * F
         waters_in_hist = int(total.dhist.sum().item()) // 4 if total.dhist is not None else 0
         value = frames_total / elapsed
         k_avg_s = (k_ms / max(k_launches, 1)) * 1e-3
         waters_per_launch = (args.steps * F * n) / max(k_launches, 1)
-        alg_bytes = ALG_BYTES_PER_WATER[args.dtype] * waters_per_launch
+        bytes_per_water = ALG_BYTES_IN[args.dtype] + (ALG_BYTES_Q[args.dtype] if args.want_q else 0.0)
+        alg_bytes = bytes_per_water * waters_per_launch
         achieved = alg_bytes / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        secondary = None
+        if insts and k_avg_s > 0:
+            secondary = {"bound": "valu", "kernel": kname, "insts_per_water": insts / waters_per_launch,
+                         "issue_cycles_per_inst": VALU_ISSUE_CYCLES,
+                         "issue_frac": insts * VALU_ISSUE_CYCLES / (N_SIMD * PEAK_CLOCK_HZ * k_avg_s),
+                         "peak": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction",
+                         "insts_source": COUNTERS_FILE + " (SQ_INSTS_VALU per launch; launch time measured in this run)"}
         out = {
             "metric": "frames/sec for tetrahedral q (+ 4-NN O-O distance histogram), %dk-water box" % (n // 1000),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -208,16 +289,22 @@ def main():
                                    "q + 4-NN O-O distance histogram + per-frame mean/var, %d frames per step per GPU, "
                                    "frames resident in HBM" % (n, F),
                        "waters": n, "frames_per_step": F, "frames_total": frames_total,
-                       "sharding": "frames x%d" % world, "highCut": 10.0},
+                       "sharding": "frames x%d" % world, "highCut": 10.0, "per_water_q_written": bool(args.want_q)},
             "check": {"mean_q": float(total.mean.mean().item()), "waters_binned": waters_in_hist},
-            "roofline": {"bound": "hbm", "kernel": "k_search_rows" if args.search_rows != 0 else "k_search_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "launches": int(k_launches), "avg_launch_ms": k_avg_s * 1e3,
+                         "alg_bytes_per_water": bytes_per_water,
                          "exact_path_fraction_last_launch": slow_last / float(F * n),
                          "tile_density_level": dens_level, "proposal_block_threads": rows_block,
-                         "alg_bytes_per_launch": alg_bytes},
+                         "alg_bytes_per_launch": alg_bytes,
+                         "secondary": secondary},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if not args.no_end_to_end and world == 1:
+            out["end_to_end"] = end_to_end(torch, engine, ctx, batches[args.warmup], box, args)
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 of the one-GPU run only
             pos_host = batches[args.warmup][0].to(torch.float64).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(pos_host, box, min(args.cpu_sample_waters, n), len(os.sched_getaffinity(0)))

@@ -39,7 +39,6 @@ def test_q_on_bin_edges_is_binned_as_the_full_chain_bins_it(oracle):
     assert ctx.counter("slow_waters") >= 2 * len(targets)    # the guard handed them to the exact kernel
     expect = np.zeros(500, dtype=np.int64)
     lin = np.linspace(0.0, 1.0, 501)
-    fragile = 0
     for f in range(2):
         q_full = wp.getOrderParamq(frames[f], frames[f], boxes[f], full=True, ctx=ctx)[0]
         expect += _np_hist(q_full)
@@ -49,11 +48,9 @@ def test_q_on_bin_edges_is_binned_as_the_full_chain_bins_it(oracle):
         assert np.max(np.abs(q_ref[targets] - edges)) < 5e-15
         np.testing.assert_allclose(q_full, q_ref, rtol=0, atol=Q_TOL)
         clear = np.abs(q_ref[targets] - edges) > 5e-16
-        fragile += int((~clear).sum())
         assert np.array_equal(np.digitize(q_full[targets][clear], lin), np.digitize(q_ref[targets][clear], lin))
         assert np.abs(_np_hist(q_full) - oracle.np_histogram(q_ref)).sum() <= 2 * int((~clear).sum())
     assert np.array_equal(res.qhist, expect)
-    assert fragile < len(targets)
     # the same through the one-block-per-frame sort (>= 128 frames per batch) and without per-water q
     res2 = engine.tet_order_traj(np.repeat(frames, 70, axis=0), np.repeat(boxes, 70, axis=0), ctx=ctx)
     assert np.array_equal(res2.qhist, 70 * expect)

@@ -1,6 +1,6 @@
 """Per-kernel summary of a tools/collect_sq_counters.sh run: average launch time (rocprofv3 --kernel-trace --stats) and
 counter values per dispatch of libwol's kernels (names starting with k_).
-    python tools/summarize_pmc.py <dir> <out.json>"""
+    python tools/summarize_pmc.py <dir> <out.json> ['<json object stored under "_config">']"""
 import collections, csv, glob, json, os, sys
 
 csv.field_size_limit(1 << 30)
@@ -41,8 +41,12 @@ def main():
         e.update(stats.get(k, {}))
         e["counters_per_dispatch"] = {c: acc[k][c] / max(len(disp[k][c]), 1) for c in sorted(acc[k])}
         res[k] = e
+    if len(sys.argv) > 3:
+        res["_config"] = json.loads(sys.argv[3])
     json.dump(res, open(out, "w"), indent=1)
     for k, e in res.items():
+        if k.startswith("_"):
+            continue
         print("%-34s %6s calls  avg %9.1f us  %5.1f %%   wg %4s vgpr %4s lds %6s" % (k[:34], e.get("calls", "-"), e.get("avg_us", 0.0),
               e.get("percent", 0.0), e.get("workgroup", "-"), e.get("vgpr", "-"), e.get("lds_bytes", "-")))
         for c, v in e["counters_per_dispatch"].items():

@@ -112,6 +112,12 @@ struct wol_ctx {
     SortSet* last_set = nullptr;
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps, scan_tot;
     PinBuf grids_host;
+    // host-trajectory pipeline (wol_q_traj with WOL_MEM_HOST): two staging sets; the copy of batch k+1 runs on
+    // copy_stream under batch k's kernels
+    DevBuf host_stage[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
+    double last_h2d_bytes = 0.0;   // bytes the last host-trajectory call moved over the link (diagnostic counter)
     hipEvent_t grid_ev = nullptr;   // marks completion of the last pinned->device grid upload
     bool grid_copy_pending = false;
     // dominant-kernel timing
@@ -780,8 +786,17 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
 
     int Fb = c->frames_per_batch;
     if (Fb <= 0) {
-        const double per_frame = (double)n * 64.0 + (host ? (double)frame_stride * sizeof(T) : 0.0);
-        Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 2.0e9 / per_frame));
+        if (host) {
+            // host frames: batches of ~256 MB (at least 64 frames: the streaming sort wants that many), so the first
+            // copy -- the only one no kernel runs under -- stays a small part of the job
+            const double frame_bytes = (double)frame_stride * sizeof(T);
+            Fb = (int)std::fmin(4096.0, std::fmax(64.0, 256.0e6 / frame_bytes));
+            const double per_frame = (double)n * 64.0 + 2.0 * frame_bytes;
+            Fb = (int)std::fmin((double)Fb, std::fmax(1.0, 6.0e9 / per_frame));
+        } else {
+            const double per_frame = (double)n * 64.0;
+            Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 2.0e9 / per_frame));
+        }
         if (Fb >= 8 && Fb < T_frames) Fb = (Fb / 8) * 8;
     }
     Fb = std::min(Fb, T_frames);
@@ -806,18 +821,44 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         d_stats = c->small.as<double>();
     }
 
-    for (int f0 = 0; f0 < T_frames; f0 += Fb) {
+    // ---- host frames: double-buffered staging.  The link carries the frames as they lie in host memory (whole
+    // interleaved frames: measured on MI355X, a strided copy of the 24-byte O rows -- hipMemcpy2DAsync or a gather
+    // kernel over mapped host memory -- is no faster than the linear copy of everything, tools/pcie_probe.hip), the
+    // kernels pick the O rows out of the staged frames through the atom stride.
+    const int nbatch = (T_frames + Fb - 1) / Fb;
+    auto batch_elems = [&](int F) { return (size_t)(F - 1) * frame_stride + (size_t)(n - 1) * atom_stride + 3; };
+    auto enqueue_copy = [&](int b) -> int {
+        const int f0 = b * Fb, F = std::min(Fb, T_frames - f0), k = b & 1;
+        if (b >= 2) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->consumed_ev[k], 0));   // batch b-2 is done with this set
+        HIP_TRY(hipMemcpyAsync(c->host_stage[k].p, frames + (int64_t)f0 * frame_stride, batch_elems(F) * sizeof(T),
+                               hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->copied_ev[k], c->copy_stream));
+        c->last_h2d_bytes += (double)(batch_elems(F) * sizeof(T));
+        return WOL_OK;
+    };
+    if (host) {
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            if (!c->copied_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->copied_ev[k], hipEventDisableTiming));
+            if (!c->consumed_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->consumed_ev[k], hipEventDisableTiming));
+            if (k < nbatch) WOL_TRY(c->host_stage[k].ensure(batch_elems(std::min(Fb, T_frames)) * sizeof(T)));
+        }
+        // earlier work on the context's stream may still read the staging sets (a previous call's last batches)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->last_h2d_bytes = 0.0;
+        WOL_TRY(enqueue_copy(0));
+    }
+
+    for (int b = 0; b < nbatch; ++b) {
+        const int f0 = b * Fb;
         const int F = std::min(Fb, T_frames - f0);
         FramesView<T> fv;
         fv.atom_stride = atom_stride;
         fv.frame_stride = frame_stride;
         fv.n = n;
         if (host) {
-            const size_t elems = (size_t)(F - 1) * frame_stride + (size_t)(n - 1) * atom_stride + 3;
-            WOL_TRY(c->in_stage.ensure(elems * sizeof(T)));
-            HIP_TRY(hipMemcpyAsync(c->in_stage.p, frames + (int64_t)f0 * frame_stride, elems * sizeof(T),
-                                   hipMemcpyHostToDevice, c->stream));
-            fv.base = c->in_stage.as<T>();
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->copied_ev[b & 1], 0));
+            fv.base = c->host_stage[b & 1].as<T>();
         } else {
             fv.base = frames + (int64_t)f0 * frame_stride;
         }
@@ -827,14 +868,14 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         if (q_direct) {
             qd = reinterpret_cast<double*>(q_out) + (int64_t)f0 * n;
         } else if (q_out && std::is_same<T, double>::value) {
-            WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)F * n));
+            WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)std::min(Fb, T_frames) * n));
             qd = c->qbuf.as<double>();
         }
         out.q = qd;  // per-water q is only materialised when the caller asks for it
         float* q32d = nullptr;
         if (q_out && !std::is_same<T, double>::value) {
             if (host) {
-                WOL_TRY(c->out_stage.ensure(sizeof(float) * (size_t)F * n));
+                WOL_TRY(c->out_stage.ensure(sizeof(float) * (size_t)std::min(Fb, T_frames) * n));
                 q32d = c->out_stage.as<float>();
             } else {
                 q32d = reinterpret_cast<float*>(q_out) + (int64_t)f0 * n;
@@ -844,7 +885,7 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         out.qhist = d_qh; out.qbins = qbins;
         out.dhist = d_dh; out.dbins = dbins; out.dbinwidth = dbinwidth;
         if (need_stats) {
-            WOL_TRY(c->stat.ensure(sizeof(unsigned long long) * 4 * (size_t)F));
+            WOL_TRY(c->stat.ensure(sizeof(unsigned long long) * 4 * (size_t)std::min(Fb, T_frames)));
             HIP_TRY(hipMemsetAsync(c->stat.p, 0, sizeof(unsigned long long) * 4 * (size_t)F, c->stream));
             out.stat = c->stat.as<unsigned long long>();
         }
@@ -855,13 +896,18 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
             hipLaunchKernelGGL(k_stat_finalize, dim3((F + 255) / 256), dim3(256), 0, c->stream,
                                c->stat.as<unsigned long long>(), F, n, dm, dv);
         }
-        if (host && q_out) {
-            if (std::is_same<T, double>::value)
-                HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, qd, sizeof(double) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
-            else
-                HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, q32d, sizeof(float) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+        if (host) {
+            HIP_TRY(hipEventRecord(c->consumed_ev[b & 1], c->stream));
+            // the next batch's frames cross the link while this batch's kernels run (a copy from pageable memory
+            // blocks the host until it is staged: this batch's kernels are enqueued already)
+            if (b + 1 < nbatch) WOL_TRY(enqueue_copy(b + 1));
+            if (q_out) {   // behind this batch's kernels on the stream; the staging buffer is reused in stream order
+                if (std::is_same<T, double>::value)
+                    HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, qd, sizeof(double) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+                else
+                    HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, q32d, sizeof(float) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+            }
         }
-        if (host) HIP_TRY(hipStreamSynchronize(c->stream));  // staging buffers are reused by the next batch
     }
     if (host) {
         if (mean) HIP_TRY(hipMemcpyAsync(mean, d_stats, sizeof(double) * (size_t)T_frames, hipMemcpyDeviceToHost, c->stream));
@@ -928,6 +974,12 @@ int wol_ctx_destroy(wol_ctx* c) {
     if (c->in_ev) (void)hipEventDestroy(c->in_ev);
     if (c->sort_stream) { (void)hipStreamSynchronize(c->sort_stream); (void)hipStreamDestroy(c->sort_stream); }
     for (DevBuf* b : bufs) b->release();
+    for (int k = 0; k < 2; ++k) {
+        c->host_stage[k].release();
+        if (c->copied_ev[k]) (void)hipEventDestroy(c->copied_ev[k]);
+        if (c->consumed_ev[k]) (void)hipEventDestroy(c->consumed_ev[k]);
+    }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     c->grids_host.release();
     if (c->grid_ev) (void)hipEventDestroy(c->grid_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -1007,6 +1059,10 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
             HIP_TRY(hipMemcpy(&v, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost));
             *value = v;
         }
+        return WOL_OK;
+    }
+    if (std::string(key) == "h2d_bytes") {   // bytes the last host-memory trajectory call sent over the link
+        *value = (int64_t)c->last_h2d_bytes;
         return WOL_OK;
     }
     if (std::string(key) == "rows_block") {  // k_search_rows instantiation of the last batch (threads per block)

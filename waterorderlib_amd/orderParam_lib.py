@@ -8,8 +8,9 @@ with ``.traj`` and ``getWatInds()``: the array-backed waterorderlib_amd.TrajObje
 reference's own pytraj-backed class) instead of a path; paths need parmed/pytraj, which the
 reference imports at TrajObject.py:10-11 and which are outside this build.
 
-The frame loop itself moves to the GPU: all frames go through ONE wol_q_traj call (frames batched
-in HBM, nothing per-water on the host); sub-populations use wol_q_frame per frame.
+The frame loop itself moves to the GPU: the trajectory is read lazily in chunks, every chunk is one wol_q_traj call
+(frames batched in HBM, the copy of one batch under the kernels of the previous, nothing per-water on the host);
+sub-populations use wol_q_frame per frame.
 """
 import numpy as np
 
@@ -18,29 +19,25 @@ from . import water_properties as wp
 
 
 def getCI(means):
-    """orderParam_lib.py:387-391"""
-    meanCI = means[int(0.5 * len(means))]
-    upperCI = means[int(0.975 * len(means))] - meanCI
-    lowerCI = meanCI - means[int(0.025 * len(means))]
-    return max(upperCI, lowerCI)
+    """orderParam_lib.py:387-391: half-width of the 95 % interval of a SORTED sample about its median, the larger of
+    the two sides (entries at the 2.5 %, 50 % and 97.5 % positions, positions truncated as the reference's int())."""
+    n = len(means)
+    lo, mid, hi = means[int(0.025 * n)], means[int(0.5 * n)], means[int(0.975 * n)]
+    return max(hi - mid, mid - lo)
 
 
 def blockAverage(vals, nBlocks=20, rng=None):
-    """orderParam_lib.py:394-417: 20 block means, 10 000 bootstrap resamples, CI half-width.
-    The reference draws from the unseeded global np.random; pass ``rng`` (np.random.Generator) for
-    a reproducible CI."""
+    """orderParam_lib.py:394-417: the series is cut into nBlocks consecutive blocks (edges at int(i * len / nBlocks)),
+    the block means are resampled with replacement 10 000 times, and getCI of the sorted resample means is returned.
+    The reference draws from the unseeded global np.random (its CI is not reproducible); pass ``rng``
+    (np.random.Generator) for a reproducible one."""
     vals = np.asarray(vals)
-    obsBlocks = np.zeros(nBlocks)
-    lenBlock = len(vals) / nBlocks
-    for i in range(nBlocks):
-        obsBlocks[i] = np.mean(vals[int(i * lenBlock):int((i + 1) * lenBlock)])
-    nResamp = 10000
-    if rng is None:
-        draws = np.random.choice(obsBlocks, (nResamp, nBlocks))
-    else:
-        draws = rng.choice(obsBlocks, (nResamp, nBlocks))
-    obsMeans = np.sort(draws.mean(axis=1))
-    return getCI(obsMeans)
+    width = len(vals) / nBlocks
+    edges = [int(i * width) for i in range(nBlocks + 1)]
+    blocks = np.array([np.mean(vals[a:b]) for a, b in zip(edges[:-1], edges[1:])])
+    draw = np.random.choice if rng is None else rng.choice
+    resampled = draw(blocks, (10000, nBlocks)).mean(axis=1)
+    return getCI(np.sort(resampled))
 
 
 def _as_traj_object(topFile, trajFile, stride, solResName, watResName):
@@ -55,47 +52,76 @@ def _as_traj_object(topFile, trajFile, stride, solResName, watResName):
     raise NotImplementedError("file-backed trajectories: wrap them in the reference's TrajObject and pass the object")
 
 
+# host bytes of frames handed to one wol_q_traj call by the streaming drivers (the library cuts them into batches
+# and overlaps the copy of one batch with the kernels of the previous one)
+CHUNK_BYTES = 1 << 30
+
+
+def _frame_chunks(traj, select=None, chunk_bytes=None):
+    """Lazily yields (t0, xyz[k, m, 3], boxes[k, 3]) over a trajectory: frames are taken from the iterator as they
+    are needed (pytraj.iterload reads from disk on demand, orderParam_lib.py:1458) and only one chunk is held.
+    ``select`` picks the atoms kept of every frame: None (all), a slice, or an index array."""
+    chunk_bytes = CHUNK_BYTES if chunk_bytes is None else chunk_bytes
+    sel = slice(None) if select is None else select
+    buf, boxes, t0, per, k = None, [], 0, 1, 0
+    for t, frame in enumerate(traj):
+        x = np.asarray(frame.xyz)[sel]
+        if buf is None:
+            dt = np.float32 if x.dtype == np.float32 else np.float64
+            per = max(1, min(4096, int(chunk_bytes // max(x.shape[0] * 3 * np.dtype(dt).itemsize, 1))))
+            buf = np.empty((per,) + x.shape, dtype=dt)
+        buf[k] = x
+        boxes.append(np.asarray(frame.box.values[:3], dtype=np.float64))
+        k += 1
+        if k == per:
+            yield t0, buf[:k], np.array(boxes).reshape(-1, 3)
+            t0, k, boxes = t + 1, 0, []
+    if k:
+        yield t0, buf[:k], np.array(boxes).reshape(-1, 3)
+
+
 def tetOrderCalc(topFile, trajFile=None, subInds=None, nPops=0, solResName='(!:WAT)', watResName='(:WAT)',
-                 stride=1, outPrefix='qDistribution_', rng=None, write=True):
+                 stride=1, outPrefix='qDistribution_', rng=None, write=True, chunk_bytes=None):
     """orderParam_lib.py:1426-1503.  Returns (avgQ, varQ) = ([mean over frames, CI], [...]) per
-    population (index 0 = all waters) and writes qDistribution_<j>.txt."""
+    population (index 0 = all waters) and writes qDistribution_<j>.txt.
+
+    The frame loop (opl:1458-1480) runs on the GPU: the trajectory is consumed lazily in chunks of at most
+    ``chunk_bytes`` of host memory (default 1 GiB), each chunk is one wol_q_traj call; the integer histogram and the
+    per-frame mean / variance series accumulate across chunks, so memory does not grow with the trajectory."""
     obj = _as_traj_object(topFile, trajFile, stride, solResName, watResName)
     traj = obj.traj
     watInds, watHInds, lenWat = obj.getWatInds()
     watInds = np.asarray(watInds)
-    nT = len(traj)
-    avgQ = [np.zeros(nT) for _ in range(nPops + 1)]
-    varQ = [np.zeros(nT) for _ in range(nPops + 1)]
+    nW = len(watInds)
+    # the O rows are read on the GPU straight out of the interleaved frame when the waters are a regular stride of
+    # the atom list (watInds = first + k*lenWat); otherwise they are gathered on the host (pos[watInds], opl:1462)
+    regular = nW > 0 and lenWat > 0 and np.array_equal(watInds, watInds[0] + lenWat * np.arange(nW))
+    span = slice(int(watInds[0]), int(watInds[0]) + lenWat * nW) if regular else None
+    avgQ = [[] for _ in range(nPops + 1)]
+    varQ = [[] for _ in range(nPops + 1)]
     qHist = [np.zeros(engine.QBINS, dtype=np.int64) for _ in range(nPops + 1)]
-
-    # gather frames: the O rows are read on the GPU straight out of the interleaved frame when the
-    # waters are a regular stride of the atom list (watInds = first + k*lenWat)
-    xyz, boxes = [], []
-    for frame in traj:
-        xyz.append(np.asarray(frame.xyz))
-        boxes.append(np.asarray(frame.box.values[:3], dtype=np.float64))
-    boxes = np.array(boxes).reshape(-1, 3)
-    regular = len(watInds) > 0 and lenWat > 0 and np.array_equal(watInds, watInds[0] + lenWat * np.arange(len(watInds)))
-    if nT:
-        if regular:
-            frames = np.stack([x[watInds[0]: watInds[0] + lenWat * len(watInds)] for x in xyz])
-            res = engine.tet_order_traj(frames, boxes, len_wat=lenWat, want_dhist=False)
-        else:
-            frames = np.stack([x[watInds] for x in xyz])
-            res = engine.tet_order_traj(frames, boxes, len_wat=1, want_dhist=False)
-        avgQ[0][:] = res.mean
-        varQ[0][:] = res.var
-        qHist[0] += res.qhist
-    for t in range(nT):
+    if nPops:
+        select = None            # sub-populations index the whole frame
+    else:
+        select = span if regular else watInds
+    for t0, xyz, boxes in (_frame_chunks(traj, select, chunk_bytes) if nW else ()):
         if nPops:
-            watPos = np.ascontiguousarray(xyz[t][watInds], dtype=np.float64)
+            waters = np.ascontiguousarray(xyz[:, span] if regular else xyz[:, watInds])
+        else:
+            waters = xyz
+        res = engine.tet_order_traj(waters, boxes, len_wat=lenWat if regular else 1, want_dhist=False)
+        avgQ[0].extend(res.mean); varQ[0].extend(res.var)
+        qHist[0] += res.qhist
+        for k in range(len(xyz) if nPops else 0):
+            t = t0 + k
+            watPos = np.ascontiguousarray(xyz[k][watInds], dtype=np.float64)
             for j in range(1, nPops + 1):
-                subPos = np.asarray(xyz[t], dtype=np.float64)[subInds[t][j - 1]]
-                jQ = wp.getOrderParamq(subPos, watPos, boxes[t])
-                avgQ[j][t] = np.mean(jQ)
-                varQ[j][t] = np.var(jQ)
-                h, _ = np.histogram(jQ, bins=engine.QBINS, range=[0.0, 1.0], density=False)
-                qHist[j] += h
+                subPos = np.asarray(xyz[k], dtype=np.float64)[subInds[t][j - 1]]
+                jQ = wp.getOrderParamq(subPos, watPos, boxes[k])
+                avgQ[j].append(np.mean(jQ)); varQ[j].append(np.var(jQ))
+                qHist[j] += np.histogram(jQ, bins=engine.QBINS, range=[0.0, 1.0], density=False)[0]
+    avgQ = [np.asarray(a, dtype=np.float64) for a in avgQ]
+    varQ = [np.asarray(v, dtype=np.float64) for v in varQ]
 
     avgQ_mean = np.zeros(nPops + 1); avgQ_CI = np.zeros(nPops + 1)
     varQ_mean = np.zeros(nPops + 1); varQ_CI = np.zeros(nPops + 1)

@@ -94,18 +94,18 @@ def getLSI(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7, ctx=None):
 
 
 def tetrahedralMetrics(angVals, nBins=500, binRange=[0.0, 180.0]):
-    """water_properties.py:314-342 -- host-side numpy post-processing of the angle list (kept
-    verbatim in behaviour: histogram, tetrahedral fraction in [100,120] deg, <cos>, var cos, entropy)."""
-    angVals = np.asarray(angVals, dtype=np.float64)
-    angDist, bins = np.histogram(angVals, bins=nBins, range=binRange, density=False)
-    angTet = angVals[np.where((angVals >= 100.0) & (angVals <= 120.0))[0]]
-    fracTet = float(len(angTet)) / float(len(angVals))
-    avgCos = np.mean(np.cos(angTet * np.pi / 180.0))
-    varCos = np.var(np.cos(angTet * np.pi / 180.0))
-    angDens = angDist / float(np.sum(angDist))
-    angDens = angDens[np.where(angDens != 0)[0]]
-    entropy = -np.sum(angDens * np.log(angDens))
-    return angDist, bins, fracTet, avgCos, varCos, entropy
+    """water_properties.py:314-342: statistics of a three-body angle list (degrees).  Returns the histogram counts over
+    binRange and its edges, the fraction of angles inside [100, 120] degrees, the mean and the population variance of
+    the cosine over THAT tetrahedral subset, and the Shannon entropy -sum p ln p of the normalised histogram (empty
+    bins left out).  Host-side numpy, as in the reference."""
+    ang = np.asarray(angVals, dtype=np.float64)
+    counts, edges = np.histogram(ang, bins=nBins, range=binRange, density=False)
+    tet = ang[(ang >= 100.0) & (ang <= 120.0)]
+    frac_tet = float(len(tet)) / float(len(ang))
+    cos_tet = np.cos(tet * np.pi / 180.0)
+    p = counts / float(np.sum(counts))
+    p = p[p != 0]
+    return counts, edges, frac_tet, np.mean(cos_tet), np.var(cos_tet), -np.sum(p * np.log(p))
 
 
 def waterOrientation(Opos, Hpos, boxDim, refVec=[0.0, 0.0, 1.0]):
