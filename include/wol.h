@@ -41,7 +41,13 @@ extern "C" {
 #define WOL_MEM_HOST 0
 #define WOL_MEM_DEVICE 1
 
+/* storage type of the caller's real arrays in the *_t entry points (arithmetic is always the reference's fp64:
+ * floats are promoted exactly on the way in and results rounded once on the way out) */
+#define WOL_F64 0
+#define WOL_F32 1
+
 typedef struct wol_ctx wol_ctx;
+typedef struct wol_comm wol_comm;   /* RCCL communicator of a frame-sharded job (one rank per GPU) */
 
 int wol_version(void);
 const char* wol_last_error(void);
@@ -63,7 +69,8 @@ int wol_ctx_synchronize(wol_ctx* ctx);
  * overlapped sort), "inputs_resident" (1 = the caller guarantees that device input buffers are complete in
  * memory when a call is made, not merely enqueued earlier on the stream, so the sort of one call may overlap
  * the previous call's kernels; default 0), "time_kernels" (0/1: HIP-event timing of the dominant kernel,
- * read back with wol_ctx_kernel_time) */
+ * read back with wol_ctx_kernel_time), "rows_block" (0 = the proposal kernel's instantiation is picked per batch by lane
+ * fill, default; 512 / 768 = force that k_search_rows instantiation: tests and tuning) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
@@ -71,7 +78,9 @@ int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int r
 
 /* diagnostic counters of the LAST q call on this context (synchronises the stream):
  * "slow_waters" = waters the fp32 filter could not certify and the exact search finished;
- * "density_level" = tile-shape level the device picked for frame 0 (0 = box-average density) */
+ * "density_level" = tile-shape level the device picked for frame 0 (0 = box-average density);
+ * "rows_block" = threads per block of the k_search_rows instantiation that ran (0: another proposal kernel);
+ * "h2d_bytes" = bytes the last host-memory trajectory call sent over the host link */
 int wol_ctx_get_counter(wol_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- level 1: the f2py `waterlib` routines on the path (host pointers) -------------------- */
@@ -102,6 +111,12 @@ int wol_q_frame(wol_ctx* ctx, const double* pos, int64_t pos_stride, int n, cons
                 int64_t sub_stride, int ns, const double* box, double lowcut, double highcut,
                 double* q, int32_t* nn_idx, double* nn_dist, double* ang_deg, int mem);
 
+/* The same with the caller's reals stored as `dtype` (WOL_F64 / WOL_F32) in `mem` (host or device): pos, sub, q,
+ * nn_dist and ang_deg are arrays of that type; nn_idx is int32 in the same memory space. */
+int wol_q_frame_t(wol_ctx* ctx, const void* pos, int64_t pos_stride, int n, const void* sub, int64_t sub_stride,
+                  int ns, const double* box, double lowcut, double highcut, void* q, int32_t* nn_idx,
+                  void* nn_dist, void* ang_deg, int dtype, int mem);
+
 /* getCosAngs (water_properties.py:210-250): all k(k-1)/2 angles per water over the shell
  * lowcut < d <= highcut, flattened in water order.  Two calls: with ang == NULL it fills
  * num_angs[ns] (= k per water, as a double like the reference's np.zeros) and *total; then with a
@@ -110,11 +125,20 @@ int wol_cos_angs(wol_ctx* ctx, const double* pos, int n, const double* sub, int 
                  const double* box, double lowcut, double highcut, double* ang, double* num_angs,
                  int64_t* total);
 
+/* typed / device-memory form: pos, sub, ang, num_angs are `dtype` arrays in `mem`; *total is always a host value
+ * (it sizes the second call's buffer), so the call synchronises the stream */
+int wol_cos_angs_t(wol_ctx* ctx, const void* pos, int n, const void* sub, int ns, const double* box,
+                   double lowcut, double highcut, void* ang, void* num_angs, int64_t* total, int dtype, int mem);
+
 /* getLSI (water_properties.py:252-311): lsi_full[ns] = LSI of water i or NaN where the reference
  * skips the water; num_lsi[ns] as wp:306; *nvalid = len(lsiVals).  Host pointers. */
 int wol_lsi_frame(wol_ctx* ctx, const double* pos, int n, const double* sub, int ns,
                   const double* box, double lowcut, double highcut, double* lsi_full,
                   double* num_lsi, int64_t* nvalid);
+
+/* typed / device-memory form; *nvalid is a host value (the call synchronises the stream) */
+int wol_lsi_frame_t(wol_ctx* ctx, const void* pos, int n, const void* sub, int ns, const double* box,
+                    double lowcut, double highcut, void* lsi_full, void* num_lsi, int64_t* nvalid, int dtype, int mem);
 
 /* ---- "next" row f-1: Willard-Chandler density field ---------------------------- */
 /* waterlib.f90:1286-1341 WillardDensityField (called by surface_library.densityGrid, :170-210):
@@ -188,6 +212,35 @@ int wol_q_traj_f32(wol_ctx* ctx, const float* frames, int64_t atom_stride, int64
                    int T, int n, const double* boxes, double lowcut, double highcut, double* mean,
                    double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,
                    double dbinwidth, float* q_out, int mem);
+
+/* ---- multi-GPU: frame shards, one exchange step ------------------------------------------
+ * The frame loop of tetOrderCalc has no dependence between frames (orderParam_lib.py:1458-1473): rank r of R (one
+ * process per GPU) owns the contiguous block of frames given by wol_shard_bounds and runs the one-GPU pipeline on it;
+ * the job ends with ONE exchange step over RCCL -- all-reduce (sum) of the int64 histograms, all-gather of the per-frame
+ * (mean, var) series.  Integer sums do not depend on the order of reduction: every rank ends up with exactly the
+ * one-GPU result. */
+/* frames [*t0, *t1) = [rank*T/world, (rank+1)*T/world) belong to `rank` */
+int wol_shard_bounds(int T_total, int rank, int world, int* t0, int* t1);
+/* Communicator.  Rank 0 calls wol_comm_unique_id (fills 128 bytes), the caller hands those bytes to every rank by
+ * whatever it has (MPI_Bcast, a file, a torch.distributed store), every rank calls wol_comm_init with its context
+ * (whose device becomes the rank's GPU).  wol_comm_adopt wraps an ncclComm_t the caller already owns.  RCCL is looked
+ * up at run time (the copy already mapped into the process, else librccl.so.1 on the loader path). */
+int wol_comm_unique_id(void* id128);
+int wol_comm_init(wol_ctx* ctx, const void* id128, int rank, int world, wol_comm** out);
+int wol_comm_adopt(void* nccl_comm, int rank, int world, wol_comm** out);
+int wol_comm_destroy(wol_comm* comm);
+/* wol_q_traj on this rank's T_local frames (frames / boxes / q_out are the LOCAL block) followed by the exchange step:
+ * qhist / dhist receive (accumulate, as wol_q_traj) the job-wide counts, mean / var [T_total] the series of all frames
+ * in trajectory order, on every rank.  Collective: every rank of the communicator must call it.  With WOL_MEM_DEVICE
+ * everything is enqueued on the context's stream. */
+int wol_q_traj_sharded(wol_ctx* ctx, wol_comm* comm, const double* frames, int64_t atom_stride, int64_t frame_stride,
+                       int T_local, int T_total, int n, const double* boxes, double lowcut, double highcut,
+                       double* mean, double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,
+                       double dbinwidth, double* q_out, int mem);
+int wol_q_traj_sharded_f32(wol_ctx* ctx, wol_comm* comm, const float* frames, int64_t atom_stride, int64_t frame_stride,
+                           int T_local, int T_total, int n, const double* boxes, double lowcut, double highcut,
+                           double* mean, double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,
+                           double dbinwidth, float* q_out, int mem);
 
 #ifdef __cplusplus
 }

@@ -197,3 +197,214 @@ def test_breathing_boxes_reuse_tile_tables(oracle):
     for t in (0, 19, 41, 59):
         np.testing.assert_allclose(res.q[t], oracle.getOrderParamq(frames[t], frames[t], bx[t], cells=True), rtol=0, atol=Q_TOL)
     ctx.close()
+
+
+def test_host_pipeline_equals_device_resident_bit_for_bit():
+    """wol_q_traj with host frames: double-buffered staging (several batches, the copy of one under the kernels of the
+    previous), TIP4P-interleaved frames read through the atom stride; float32 wire format; per-water q on and off"""
+    import torch
+    from waterorderlib_amd import _lib, engine, synth
+    xyz, boxes = synth.water_frames(3000, 45, seed=88, len_wat=4)
+    dev = engine.tet_order_traj(torch.from_numpy(xyz).cuda(), boxes, len_wat=4, want_q=True)
+    torch.cuda.synchronize()
+    ctx = _lib.Context(0)
+    for fpb in (8, 16, 0):                       # 6 batches (last one ragged), 3 batches, automatic (one batch)
+        ctx.set_option("frames_per_batch", fpb)
+        for want_q in (True, False):
+            res = engine.tet_order_traj(xyz, boxes, len_wat=4, want_q=want_q, ctx=ctx)
+            assert np.array_equal(res.qhist, dev.qhist.cpu().numpy()) and np.array_equal(res.dhist, dev.dhist.cpu().numpy())
+            assert np.array_equal(res.mean, dev.mean.cpu().numpy()) and np.array_equal(res.var, dev.var.cpu().numpy())
+            if want_q:
+                assert np.array_equal(res.q, dev.q.cpu().numpy())
+        moved = ctx.counter("h2d_bytes")
+        assert 0.99 * xyz.nbytes <= moved <= xyz.nbytes       # whole interleaved frames cross the link, once
+    # back-to-back calls reuse the staging sets: the second must not overtake the first's kernels
+    a = engine.tet_order_traj(xyz[:20], boxes[:20], len_wat=4, want_q=True, ctx=ctx)
+    b = engine.tet_order_traj(xyz[20:], boxes[20:], len_wat=4, want_q=True, ctx=ctx)
+    assert np.array_equal(np.concatenate([a.q, b.q]), dev.q.cpu().numpy())
+    x32 = xyz.astype(np.float32)
+    ctx.set_option("frames_per_batch", 8)
+    r32 = engine.tet_order_traj(x32, boxes, len_wat=4, want_q=True, ctx=ctx)
+    d32 = engine.tet_order_traj(torch.from_numpy(x32).cuda(), boxes, len_wat=4, want_q=True)
+    assert np.array_equal(r32.q, d32.q.cpu().numpy()) and np.array_equal(r32.qhist, d32.qhist.cpu().numpy())
+    ctx.close()
+
+
+def test_streamed_tetordercalc_equals_one_call(tmp_path, monkeypatch):
+    """orderParam_lib.tetOrderCalc consumes the trajectory lazily, chunk by chunk (the reference iterates
+    pytraj.iterload, orderParam_lib.py:1458): a one-shot frame generator, chunks of 7 frames, result = one-call result"""
+    from waterorderlib_amd import engine, synth
+    from waterorderlib_amd import orderParam_lib as opl
+    from waterorderlib_amd.TrajObject import Frame, TrajObject
+    monkeypatch.chdir(tmp_path)
+    xyz, boxes = synth.water_frames(1500, 40, seed=89, len_wat=3)
+    alive = {"made": 0}
+
+    class OneShot:
+        """frames exist only while they are being read: a generator that can be walked once"""
+        def __init__(self):
+            self.used = False
+        def __len__(self):
+            return len(xyz)
+        def __iter__(self):
+            assert not self.used, "the trajectory was iterated twice"
+            self.used = True
+            for t in range(len(xyz)):
+                alive["made"] += 1
+                yield Frame(xyz[t].copy(), boxes[t])
+
+    obj = TrajObject(xyz[:1], boxes[:1], lenWat=3)
+    obj.traj = OneShot()
+    chunk = 7 * xyz[0].nbytes
+    avgQ, varQ = opl.tetOrderCalc(obj, rng=np.random.default_rng(1), chunk_bytes=chunk)
+    assert alive["made"] == 40
+    series_avg, series_var, hists = opl.tetOrderCalc.last_series
+    one = engine.tet_order_traj(xyz, boxes, len_wat=3)
+    assert np.array_equal(series_avg[0], one.mean) and np.array_equal(series_var[0], one.var)
+    assert np.array_equal(hists[0], one.qhist)
+    assert abs(avgQ[0][0] - np.mean(one.mean)) < 1e-15
+    assert np.loadtxt("qDistribution_0.txt")[:, 1].sum() == one.qhist.sum()
+    # irregular water selection (not a constant stride): host-side gather per frame, same numbers for those waters
+    sel = np.sort(np.random.default_rng(3).choice(1500, 1200, replace=False)) * 3
+    obj2 = TrajObject(xyz, boxes, lenWat=3)
+    obj2.getWatInds = lambda: (sel, np.array([], dtype=int), 3)
+    opl.tetOrderCalc(obj2, rng=np.random.default_rng(1), chunk_bytes=chunk, write=False)
+    ref = engine.tet_order_traj(np.ascontiguousarray(xyz[:, sel]), boxes)
+    assert np.array_equal(opl.tetOrderCalc.last_series[0][0], ref.mean) and np.array_equal(opl.tetOrderCalc.last_series[2][0], ref.qhist)
+
+
+def test_typed_and_device_forms_of_the_per_frame_calls(oracle):
+    """T in {double, float}, host or device memory for wol_q_frame / wol_cos_angs / wol_lsi_frame.
+    Device doubles reproduce the host-double call bit for bit; float storage = the double call on the float-rounded
+    coordinates with every real output rounded once to float (indices unchanged)."""
+    import ctypes as C
+    import torch
+    from waterorderlib_amd import _lib, synth
+    from waterorderlib_amd import water_properties as wp
+    xyz, boxes = synth.water_frames(4000, 1, seed=61)
+    pos, box = xyz[0], boxes[0]
+    sub = pos[100:900:3].copy()
+    for s_np in (None, sub):
+        s64 = pos if s_np is None else s_np
+        q, idx, dist, ang = wp.getOrderParamq(s64, pos, box, full=True)
+        ca, cn = wp.getCosAngs(s64, pos, box)
+        li, ln = wp.getLSI(s64, pos, box)
+        # device doubles
+        P = torch.from_numpy(pos).cuda(); S = None if s_np is None else torch.from_numpy(s_np).cuda()
+        dq, didx, ddist, dang = wp.getOrderParamq_dev(S, P, box, full=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(dq.cpu().numpy(), q) and np.array_equal(didx.cpu().numpy(), idx)
+        assert np.array_equal(ddist.cpu().numpy(), dist, equal_nan=True) and np.array_equal(dang.cpu().numpy(), ang, equal_nan=True)
+        dca, dcn = wp.getCosAngs_dev(S, P, box)
+        dli, dln = wp.getLSI_dev(S, P, box)
+        assert np.array_equal(dca.cpu().numpy(), ca) and np.array_equal(dcn.cpu().numpy(), cn)
+        assert np.array_equal(dli.cpu().numpy(), li) and np.array_equal(dln.cpu().numpy(), ln)
+        # float storage, device and host: the double result of the rounded coordinates, rounded once
+        p32 = pos.astype(np.float32); s32 = None if s_np is None else s_np.astype(np.float32)
+        rq, ridx, rdist, rang = wp.getOrderParamq(p32.astype(np.float64) if s32 is None else s32.astype(np.float64), p32.astype(np.float64), box, full=True)
+        P32 = torch.from_numpy(p32).cuda(); S32 = None if s32 is None else torch.from_numpy(s32).cuda()
+        fq, fidx, fdist, fang = wp.getOrderParamq_dev(S32, P32, box, full=True)
+        torch.cuda.synchronize()
+        assert fq.dtype == torch.float32 and np.array_equal(fidx.cpu().numpy(), ridx)
+        assert np.array_equal(fq.cpu().numpy(), rq.astype(np.float32)) and np.array_equal(fdist.cpu().numpy(), rdist.astype(np.float32), equal_nan=True)
+        assert np.array_equal(fang.cpu().numpy(), rang.astype(np.float32), equal_nan=True)
+        rca, rcn = wp.getCosAngs(p32.astype(np.float64) if s32 is None else s32.astype(np.float64), p32.astype(np.float64), box)
+        fca, fcn = wp.getCosAngs_dev(S32, P32, box)
+        assert np.array_equal(fca.cpu().numpy(), rca.astype(np.float32)) and np.array_equal(fcn.cpu().numpy(), rcn.astype(np.float32))
+        rli, rln = wp.getLSI(p32.astype(np.float64) if s32 is None else s32.astype(np.float64), p32.astype(np.float64), box)
+        fli, fln = wp.getLSI_dev(S32, P32, box)
+        assert np.array_equal(fli.cpu().numpy(), rli.astype(np.float32)) and np.array_equal(fln.cpu().numpy(), rln.astype(np.float32))
+        # float storage in HOST memory, straight through ctypes
+        ns = len(p32) if s32 is None else len(s32)
+        hq = np.zeros(ns, dtype=np.float32); hidx = np.zeros((ns, 4), dtype=np.int32)
+        hdist = np.zeros((ns, 4), dtype=np.float32); hang = np.zeros((ns, 6), dtype=np.float32)
+        ctx = _lib.default_context()
+        _lib.check(_lib.load().wol_q_frame_t(ctx.handle, _lib.ptr(p32), 3, len(p32), _lib.ptr(s32), 3, ns, _lib.ptr(_lib.box3(box)), 0.0, 10.0,
+                                             _lib.ptr(hq), _lib.ptr(hidx), _lib.ptr(hdist), _lib.ptr(hang), _lib.F32, _lib.MEM_HOST))
+        assert np.array_equal(hq, rq.astype(np.float32)) and np.array_equal(hidx, ridx) and np.array_equal(hang, rang.astype(np.float32), equal_nan=True)
+        tot = C.c_int64(0); hnum = np.zeros(ns, dtype=np.float32)
+        args = (ctx.handle, _lib.ptr(p32), len(p32), _lib.ptr(s32), ns, _lib.ptr(_lib.box3(box)), 0.0, 3.413)
+        _lib.check(_lib.load().wol_cos_angs_t(*args, None, _lib.ptr(hnum), C.byref(tot), _lib.F32, _lib.MEM_HOST))
+        hca = np.zeros(tot.value, dtype=np.float32)
+        _lib.check(_lib.load().wol_cos_angs_t(*args, _lib.ptr(hca), _lib.ptr(hnum), C.byref(tot), _lib.F32, _lib.MEM_HOST))
+        assert np.array_equal(hca, rca.astype(np.float32)) and np.array_equal(hnum, rcn.astype(np.float32))
+        hl = np.zeros(ns, dtype=np.float32); hn = np.zeros(ns, dtype=np.float32); nv = C.c_int64(0)
+        _lib.check(_lib.load().wol_lsi_frame_t(ctx.handle, _lib.ptr(p32), len(p32), _lib.ptr(s32), ns, _lib.ptr(_lib.box3(box)), 0.0, 3.7,
+                                               _lib.ptr(hl), _lib.ptr(hn), C.byref(nv), _lib.F32, _lib.MEM_HOST))
+        assert nv.value == len(rli) and np.array_equal(hl[~np.isnan(hl)], rli.astype(np.float32)) and np.array_equal(hn, rln.astype(np.float32))
+    # against the oracle too (device doubles)
+    q_o = oracle.getOrderParamq(pos, pos, box, cells=True)
+    np.testing.assert_allclose(wp.getOrderParamq_dev(None, torch.from_numpy(pos).cuda(), box).cpu().numpy(), q_o, rtol=0, atol=Q_TOL)
+
+
+def test_sharded_entry_of_the_c_abi_one_rank_over_rccl():
+    """wol_q_traj_sharded with a one-rank RCCL communicator (all a one-GPU box can hold): the exchange step runs through
+    RCCL inside the library and must leave the one-GPU result untouched; host and device memory, float32 storage"""
+    import torch
+    from waterorderlib_amd import _lib, engine, synth
+    xyz, boxes = synth.water_frames(2500, 24, seed=62, len_wat=3)
+    ctx = _lib.Context(0)
+    comm = _lib.Comm(ctx, 0, 1, _lib.Comm.unique_id())
+    assert _lib.shard_bounds(24, 0, 1) == (0, 24) and _lib.shard_bounds(10, 2, 4) == (5, 7)
+    one = engine.tet_order_traj(xyz, boxes, len_wat=3, want_q=True)
+    res = engine.tet_order_traj_sharded_rccl(xyz, boxes, 24, comm, len_wat=3, want_q=True)
+    assert np.array_equal(res.qhist, one.qhist) and np.array_equal(res.dhist, one.dhist)
+    assert np.array_equal(res.mean, one.mean) and np.array_equal(res.var, one.var) and np.array_equal(res.q, one.q)
+    dev = engine.tet_order_traj_sharded_rccl(torch.from_numpy(xyz).cuda(), boxes, 24, comm, len_wat=3, want_q=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.qhist.cpu().numpy(), one.qhist) and np.array_equal(dev.dhist.cpu().numpy(), one.dhist)
+    assert np.array_equal(dev.mean.cpu().numpy(), one.mean) and np.array_equal(dev.var.cpu().numpy(), one.var)
+    assert np.array_equal(dev.q.cpu().numpy(), one.q)
+    x32 = xyz.astype(np.float32)
+    a = engine.tet_order_traj_sharded_rccl(x32, boxes, 24, comm, len_wat=3)
+    b = engine.tet_order_traj(x32, boxes, len_wat=3)
+    assert np.array_equal(a.qhist, b.qhist) and np.array_equal(a.mean, b.mean)
+    with pytest.raises(_lib.WolError):        # a block that is not this rank's share of the trajectory
+        engine.tet_order_traj_sharded_rccl(xyz[:10], boxes[:10], 24, comm, len_wat=3)
+    comm.close(); ctx.close()
+
+
+def _two_rank_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from waterorderlib_amd import _lib, engine, synth
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    xyz, boxes = synth.water_frames(2000, 25, seed=63)
+    a, b = engine.shard_bounds(25, rank, world)
+    ctx = _lib.Context(rank)
+    # (i) the torch.distributed exchange (what bench.py uses)
+    r1 = engine.tet_order_traj_sharded(torch.from_numpy(xyz[a:b]).cuda(), boxes[a:b], 25, a, ctx=ctx)
+    # (ii) the library's own exchange over RCCL
+    comm = _lib.Comm.from_torch_distributed(ctx)
+    r2 = engine.tet_order_traj_sharded_rccl(xyz[a:b], boxes[a:b], 25, comm)
+    torch.cuda.synchronize()
+    q.put((rank, r1.qhist.cpu().numpy(), r1.mean.cpu().numpy(), r2.qhist, r2.dhist, r2.mean, r2.var))
+    dist.barrier()
+    comm.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl_when_two_gpus_are_present():
+    """the real multi-GPU path: two ranks, one GPU each, backend nccl (= RCCL); skipped on a one-GPU box"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    from waterorderlib_amd import engine, synth
+    xyz, boxes = synth.water_frames(2000, 25, seed=63)
+    one = engine.tet_order_traj(xyz, boxes)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, 29541, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    for rank, qh1, m1, qh2, dh2, m2, v2 in got:
+        assert np.array_equal(qh1, one.qhist) and np.array_equal(m1, one.mean)
+        assert np.array_equal(qh2, one.qhist) and np.array_equal(dh2, one.dhist) and np.array_equal(m2, one.mean) and np.array_equal(v2, one.var)

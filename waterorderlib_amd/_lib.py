@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WOL_LIB_PATH") or os.path.join(_HERE, "libwol.so")  # env override: tuning builds
 
 MEM_HOST, MEM_DEVICE = 0, 1
+F64, F32 = 0, 1
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -22,7 +23,10 @@ SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy",
            "wol_q_frame", "wol_cos_angs", "wol_lsi_frame", "wol_q_traj", "wol_q_traj_f32",
            "wol_willard_density_field", "wol_willard_density_points",
            "wol_radial_dist_same", "wol_radial_dist", "wol_pair_distance_histogram",
-           "wol_wat_orient", "wol_wat_oh_vec", "wol_general_hbonds", "wol_general_hbonds_list"]
+           "wol_wat_orient", "wol_wat_oh_vec", "wol_general_hbonds", "wol_general_hbonds_list",
+           "wol_q_frame_t", "wol_cos_angs_t", "wol_lsi_frame_t",
+           "wol_shard_bounds", "wol_comm_unique_id", "wol_comm_init", "wol_comm_adopt", "wol_comm_destroy",
+           "wol_q_traj_sharded", "wol_q_traj_sharded_f32"]
 
 _lib = None
 
@@ -48,6 +52,28 @@ def _preload_hip_runtime():
     cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
     if os.path.exists(cand):
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def _preload_torch_rccl():
+    """libwol resolves RCCL at run time and prefers the copy the process already maps; next to PyTorch-ROCm that must
+    be torch's bundled librccl (same reason as the HIP runtime above).  Importing torch maps it; without torch in the
+    process this maps it from the wheel if there is one, else libwol falls back to the system's librccl.so.1."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -92,6 +118,18 @@ def load():
             C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]
     L.wol_q_traj.argtypes = traj
     L.wol_q_traj_f32.argtypes = traj
+    L.wol_q_frame_t.argtypes = L.wol_q_frame.argtypes[:-1] + [C.c_int, C.c_int]
+    L.wol_cos_angs_t.argtypes = L.wol_cos_angs.argtypes + [C.c_int, C.c_int]
+    L.wol_lsi_frame_t.argtypes = L.wol_lsi_frame.argtypes + [C.c_int, C.c_int]
+    L.wol_shard_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.wol_comm_unique_id.argtypes = [_vp]
+    L.wol_comm_init.argtypes = [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]
+    L.wol_comm_adopt.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(_vp)]
+    L.wol_comm_destroy.argtypes = [_vp]
+    sharded = [_vp, _vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, _vp,
+               C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]
+    L.wol_q_traj_sharded.argtypes = sharded
+    L.wol_q_traj_sharded_f32.argtypes = sharded
     _lib = L
     return L
 
@@ -155,6 +193,59 @@ class Context:
         n = C.c_int64(0)
         check(load().wol_ctx_kernel_time(self.handle, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
+
+
+class Comm:
+    """RCCL communicator of a frame-sharded job (include/wol.h: wol_comm_*), one rank per GPU.  Rank 0 creates the
+    128-byte unique id (Comm.unique_id()), the caller distributes it, every rank constructs Comm(ctx, rank, world, id)."""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        _preload_torch_rccl()
+        h = _vp()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(load().wol_comm_init(ctx.handle, buf, int(rank), int(world), C.byref(h)))
+        self._h, self.rank, self.world, self.ctx = h, int(rank), int(world), ctx
+
+    @staticmethod
+    def unique_id():
+        _preload_torch_rccl()
+        buf = C.create_string_buffer(128)
+        check(load().wol_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_distributed(cls, ctx, group=None):
+        """the unique id travels through the (already initialised) torch.distributed process group"""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(ctx, rank, world, box[0])
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise WolError("communicator is closed")
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().wol_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_bounds(T, rank, world):
+    a, b = C.c_int(0), C.c_int(0)
+    check(load().wol_shard_bounds(int(T), int(rank), int(world), C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 _default_ctx = {}

@@ -5,6 +5,9 @@
 #include "wol_search_rows.hip"
 #include "wol_shell.hip"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the library is resolved at run time (wol_comm_*), never linked
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -112,6 +115,7 @@ struct wol_ctx {
     SortSet* last_set = nullptr;
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps, scan_tot;
     PinBuf grids_host;
+    DevBuf cvt_in, cvt_out[4], xchg;   // float <-> double conversion staging of the typed per-frame calls; exchange buffer of the sharded call
     // host-trajectory pipeline (wol_q_traj with WOL_MEM_HOST): two staging sets; the copy of batch k+1 runs on
     // copy_stream under batch k's kernels
     DevBuf host_stage[2];
@@ -711,7 +715,76 @@ int launch_cell_scan(wol_ctx* c, hipStream_t st, const FrameGrid* grids, int* ce
 
 // Single-frame set-up shared by wol_cos_angs / wol_lsi_frame: upload, bin, cell-sort; the grid is
 // built for the given reach so walking cells [-lo, hi]^3 sees every neighbour inside it.
-int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+// Where a caller's array of reals lives and how it is stored: the per-frame calls accept double or float storage in host
+// or device memory (include/wol.h: WOL_F64 / WOL_F32, WOL_MEM_HOST / WOL_MEM_DEVICE); the arithmetic is always the
+// reference's fp64 (floats are promoted exactly on the way in, results rounded once on the way out).
+struct RealSrc { const void* p; int dtype; int mem; };
+
+__global__ void k_cvt_f32_f64(const float* __restrict__ src, double* __restrict__ dst, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = (double)src[i];
+}
+__global__ void k_cvt_f64_f32(const double* __restrict__ src, float* __restrict__ dst, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = (float)src[i];
+}
+__global__ void k_int_to_f64(const int* __restrict__ src, double* __restrict__ dst, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = (double)src[i];
+}
+__global__ void k_add_u64(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] += src[i];
+}
+
+// `count` reals of the caller -> doubles at dev_dst (device), on the context's stream
+int fetch_f64(wol_ctx* c, RealSrc src, size_t count, double* dev_dst) {
+    if (count == 0) return WOL_OK;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    if (src.dtype == WOL_F64) {
+        HIP_TRY(hipMemcpyAsync(dev_dst, src.p, sizeof(double) * count,
+                               src.mem == WOL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+        return WOL_OK;
+    }
+    const float* f = static_cast<const float*>(src.p);
+    if (src.mem == WOL_MEM_HOST) {
+        WOL_TRY(c->cvt_in.ensure(sizeof(float) * count));
+        HIP_TRY(hipMemcpyAsync(c->cvt_in.p, src.p, sizeof(float) * count, hipMemcpyHostToDevice, c->stream));
+        f = c->cvt_in.as<float>();
+    }
+    hipLaunchKernelGGL(k_cvt_f32_f64, dim3(blocks), dim3(256), 0, c->stream, f, dev_dst, (int64_t)count);
+    return WOL_OK;
+}
+
+// `count` doubles at dev_src (device) -> the caller's array, on the context's stream (host destinations are complete
+// once the stream has been synchronised); `slot` picks one of the conversion staging buffers so several float
+// outputs of one call can be in flight
+int deliver_f64(wol_ctx* c, const double* dev_src, void* dst, size_t count, int dtype, int mem, int slot = 0) {
+    if (count == 0 || !dst) return WOL_OK;
+    if (dtype == WOL_F64) {
+        HIP_TRY(hipMemcpyAsync(dst, dev_src, sizeof(double) * count,
+                               mem == WOL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+        return WOL_OK;
+    }
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    if (mem == WOL_MEM_DEVICE) {
+        hipLaunchKernelGGL(k_cvt_f64_f32, dim3(blocks), dim3(256), 0, c->stream, dev_src, static_cast<float*>(dst), (int64_t)count);
+        return WOL_OK;
+    }
+    DevBuf& b = c->cvt_out[slot & 3];
+    WOL_TRY(b.ensure(sizeof(float) * count));
+    hipLaunchKernelGGL(k_cvt_f64_f32, dim3(blocks), dim3(256), 0, c->stream, dev_src, b.as<float>(), (int64_t)count);
+    HIP_TRY(hipMemcpyAsync(dst, b.p, sizeof(float) * count, hipMemcpyDeviceToHost, c->stream));
+    return WOL_OK;
+}
+
+int check_real(int dtype, int mem) {
+    if (dtype != WOL_F64 && dtype != WOL_F32) return fail(WOL_ERR_INVALID, "bad dtype (WOL_F64 or WOL_F32)");
+    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    return WOL_OK;
+}
+
+int shell_setup(wol_ctx* c, RealSrc pos, int n, RealSrc sub, int ns, const double* box,
                 double reach, ShellArgs* sa) {
     if (c->grid_copy_pending) {
         HIP_TRY(hipEventSynchronize(c->grid_ev));
@@ -726,15 +799,15 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
     const bool ok = make_grid(box, n, reach < 5.0 ? reach * 1.001 : std::fmax(reach * 0.5, 2.5), reach, gh);
     if (!ok) { gh->ncell = 1; for (int k = 0; k < 3; ++k) gh->nc[k] = 1; }
     gh->cell_base = 0;
-    const size_t pe = 3 * (size_t)n, se = sub ? 3 * (size_t)ns : 0;
+    const size_t pe = 3 * (size_t)n, se = sub.p ? 3 * (size_t)ns : 0;
     WOL_TRY(c->in_stage.ensure(sizeof(double) * (pe + se)));
     WOL_TRY(S.grids.ensure(sizeof(FrameGrid)));
     WOL_TRY(S.cells.ensure(sizeof(int) * (size_t)(gh->ncell + 1)));
     WOL_TRY(S.sorted.ensure(sizeof(double4) * (size_t)n));
     WOL_TRY(c->cellid.ensure(sizeof(int) * (size_t)n));
     WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)n));
-    HIP_TRY(hipMemcpyAsync(c->in_stage.p, pos, sizeof(double) * pe, hipMemcpyHostToDevice, c->stream));
-    if (sub) HIP_TRY(hipMemcpyAsync(c->in_stage.as<double>() + pe, sub, sizeof(double) * se, hipMemcpyHostToDevice, c->stream));
+    WOL_TRY(fetch_f64(c, pos, pe, c->in_stage.as<double>()));
+    if (sub.p) WOL_TRY(fetch_f64(c, sub, se, c->in_stage.as<double>() + pe));
     HIP_TRY(hipMemcpyAsync(S.grids.p, gh, sizeof(FrameGrid), hipMemcpyHostToDevice, c->stream));
     if (!c->grid_ev) HIP_TRY(hipEventCreateWithFlags(&c->grid_ev, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(c->grid_ev, c->stream));
@@ -755,10 +828,15 @@ int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns,
     sa->sorted = S.sorted.as<double4>();
     sa->cell_start = S.cells.as<int>();
     sa->n = n;
-    sa->sub = sub ? c->in_stage.as<double>() + pe : nullptr;
-    sa->ns = sub ? ns : n;
+    sa->sub = sub.p ? c->in_stage.as<double>() + pe : nullptr;
+    sa->ns = sub.p ? ns : n;
     sa->use_cells = ok ? 1 : 0;
     return WOL_OK;
+}
+
+int shell_setup(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+                double reach, ShellArgs* sa) {
+    return shell_setup(c, RealSrc{pos, WOL_F64, WOL_MEM_HOST}, n, RealSrc{sub, WOL_F64, WOL_MEM_HOST}, ns, box, reach, sa);
 }
 
 int check_ctx(wol_ctx* c) {
@@ -974,6 +1052,8 @@ int wol_ctx_destroy(wol_ctx* c) {
     if (c->in_ev) (void)hipEventDestroy(c->in_ev);
     if (c->sort_stream) { (void)hipStreamSynchronize(c->sort_stream); (void)hipStreamDestroy(c->sort_stream); }
     for (DevBuf* b : bufs) b->release();
+    c->cvt_in.release(); c->xchg.release();
+    for (auto& b : c->cvt_out) b.release();
     for (int k = 0; k < 2; ++k) {
         c->host_stage[k].release();
         if (c->copied_ev[k]) (void)hipEventDestroy(c->copied_ev[k]);
@@ -1175,86 +1255,100 @@ int wol_lsi_dists(wol_ctx* c, const double* refpos, const double* neigh, int n, 
 }
 
 // ---- level 2 ------------------------------------------------------------------------------
-int wol_q_frame(wol_ctx* c, const double* pos, int64_t pos_stride, int n, const double* sub, int64_t sub_stride,
-                int ns, const double* box, double lowcut, double highcut, double* q, int32_t* nn_idx,
-                double* nn_dist, double* ang_deg, int mem) {
+int wol_q_frame_t(wol_ctx* c, const void* pos, int64_t pos_stride, int n, const void* sub, int64_t sub_stride,
+                  int ns, const double* box, double lowcut, double highcut, void* q, int32_t* nn_idx,
+                  void* nn_dist, void* ang_deg, int dtype, int mem) {
     WOL_TRY(check_ctx(c));
+    WOL_TRY(check_real(dtype, mem));
     if (!pos || !box || !q) return fail(WOL_ERR_INVALID, "q_frame: pos, box and q must not be NULL");
     if (n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "q_frame: negative size");
     if (pos_stride < 3 || (sub && sub_stride < 3)) return fail(WOL_ERR_INVALID, "q_frame: stride must be >= 3");
-    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
     if (!sub) { ns = n; }
     if (ns == 0) return WOL_OK;
     const bool host = (mem == WOL_MEM_HOST);
+    const bool direct = !host && dtype == WOL_F64;   // device doubles: kernels read and write the caller's arrays
+    const size_t esz = dtype == WOL_F64 ? sizeof(double) : sizeof(float);
     QOut out;
     memset(&out, 0, sizeof out);
     FramesView<double> fv;
     fv.atom_stride = pos_stride;
     fv.frame_stride = 0;
     fv.n = n;
-    const double* dsub = sub;
+    const double* dsub = static_cast<const double*>(sub);
     if (n == 0) {
         // no candidates at all: every q is 0 (wp:358), padded outputs
-        std::vector<double> zq((size_t)ns, 0.0);
-        if (host) {
-            memcpy(q, zq.data(), sizeof(double) * (size_t)ns);
-            if (nn_idx) for (size_t k = 0; k < (size_t)ns * 4; ++k) nn_idx[k] = -1;
-            if (nn_dist) for (size_t k = 0; k < (size_t)ns * 4; ++k) nn_dist[k] = NAN;
-            if (ang_deg) for (size_t k = 0; k < (size_t)ns * 6; ++k) ang_deg[k] = NAN;
-            return WOL_OK;
+        if (!host) return fail(WOL_ERR_INVALID, "q_frame: n == 0 with device buffers is not supported");
+        memset(q, 0, esz * (size_t)ns);
+        if (nn_idx) for (size_t k = 0; k < (size_t)ns * 4; ++k) nn_idx[k] = -1;
+        for (size_t k = 0; k < (size_t)ns * 4 && nn_dist; ++k) {
+            if (dtype == WOL_F64) static_cast<double*>(nn_dist)[k] = NAN; else static_cast<float*>(nn_dist)[k] = NAN;
         }
-        return fail(WOL_ERR_INVALID, "q_frame: n == 0 with device buffers is not supported");
+        for (size_t k = 0; k < (size_t)ns * 6 && ang_deg; ++k) {
+            if (dtype == WOL_F64) static_cast<double*>(ang_deg)[k] = NAN; else static_cast<float*>(ang_deg)[k] = NAN;
+        }
+        return WOL_OK;
     }
-    size_t o_q = 0, o_idx = 0, o_dist = 0, o_ang = 0, o_total = 0;
-    if (host) {
+    size_t o_dist = 0, o_ang = 0, o_idx = 0, o_total = 0;
+    if (direct) {
+        fv.base = static_cast<const double*>(pos);
+        out.q = static_cast<double*>(q); out.nn_idx = nn_idx;
+        out.nn_dist = static_cast<double*>(nn_dist); out.ang = static_cast<double*>(ang_deg);
+    } else {
         const size_t pe = (size_t)(n - 1) * pos_stride + 3;
         const size_t se = sub ? (size_t)(ns - 1) * sub_stride + 3 : 0;
         WOL_TRY(c->in_stage.ensure(sizeof(double) * (pe + se)));
-        HIP_TRY(hipMemcpyAsync(c->in_stage.p, pos, sizeof(double) * pe, hipMemcpyHostToDevice, c->stream));
+        WOL_TRY(fetch_f64(c, RealSrc{pos, dtype, mem}, pe, c->in_stage.as<double>()));
         fv.base = c->in_stage.as<double>();
         if (sub) {
-            HIP_TRY(hipMemcpyAsync(c->in_stage.as<double>() + pe, sub, sizeof(double) * se, hipMemcpyHostToDevice, c->stream));
+            WOL_TRY(fetch_f64(c, RealSrc{sub, dtype, mem}, se, c->in_stage.as<double>() + pe));
             dsub = c->in_stage.as<double>() + pe;
         }
-        o_q = 0; o_total = sizeof(double) * (size_t)ns;
+        o_total = sizeof(double) * (size_t)ns;
         if (nn_dist) { o_dist = o_total; o_total += sizeof(double) * 4 * (size_t)ns; }
         if (ang_deg) { o_ang = o_total; o_total += sizeof(double) * 6 * (size_t)ns; }
-        if (nn_idx) { o_idx = o_total; o_total += sizeof(int32_t) * 4 * (size_t)ns; }
+        if (nn_idx && host) { o_idx = o_total; o_total += sizeof(int32_t) * 4 * (size_t)ns; }
         WOL_TRY(c->out_stage.ensure(o_total));
         char* ob = c->out_stage.as<char>();
-        out.q = reinterpret_cast<double*>(ob + o_q);
+        out.q = reinterpret_cast<double*>(ob);
         out.nn_dist = nn_dist ? reinterpret_cast<double*>(ob + o_dist) : nullptr;
         out.ang = ang_deg ? reinterpret_cast<double*>(ob + o_ang) : nullptr;
-        out.nn_idx = nn_idx ? reinterpret_cast<int32_t*>(ob + o_idx) : nullptr;
-    } else {
-        fv.base = pos;
-        out.q = q; out.nn_idx = nn_idx; out.nn_dist = nn_dist; out.ang = ang_deg;
+        out.nn_idx = !nn_idx ? nullptr : host ? reinterpret_cast<int32_t*>(ob + o_idx) : nn_idx;
     }
     WOL_TRY(run_q_batch<double>(c, fv, 1, box, dsub, sub_stride, ns, lowcut, highcut, out));
-    if (host) {
-        char* ob = c->out_stage.as<char>();
-        HIP_TRY(hipMemcpyAsync(q, ob + o_q, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-        if (nn_dist) HIP_TRY(hipMemcpyAsync(nn_dist, ob + o_dist, sizeof(double) * 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-        if (ang_deg) HIP_TRY(hipMemcpyAsync(ang_deg, ob + o_ang, sizeof(double) * 6 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-        if (nn_idx) HIP_TRY(hipMemcpyAsync(nn_idx, ob + o_idx, sizeof(int32_t) * 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!direct) {
+        WOL_TRY(deliver_f64(c, out.q, q, (size_t)ns, dtype, mem, 0));
+        WOL_TRY(deliver_f64(c, out.nn_dist, nn_dist, 4 * (size_t)ns, dtype, mem, 1));
+        WOL_TRY(deliver_f64(c, out.ang, ang_deg, 6 * (size_t)ns, dtype, mem, 2));
+        if (nn_idx && host) HIP_TRY(hipMemcpyAsync(nn_idx, out.nn_idx, sizeof(int32_t) * 4 * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+        if (host) HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return WOL_OK;
 }
 
-int wol_cos_angs(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
-                 double lowcut, double highcut, double* ang, double* num_angs, int64_t* total) {
+int wol_q_frame(wol_ctx* c, const double* pos, int64_t pos_stride, int n, const double* sub, int64_t sub_stride,
+                int ns, const double* box, double lowcut, double highcut, double* q, int32_t* nn_idx,
+                double* nn_dist, double* ang_deg, int mem) {
+    return wol_q_frame_t(c, pos, pos_stride, n, sub, sub_stride, ns, box, lowcut, highcut, q, nn_idx, nn_dist, ang_deg, WOL_F64, mem);
+}
+
+int wol_cos_angs_t(wol_ctx* c, const void* pos, int n, const void* sub, int ns, const double* box,
+                   double lowcut, double highcut, void* ang, void* num_angs, int64_t* total, int dtype, int mem) {
     WOL_TRY(check_ctx(c));
+    WOL_TRY(check_real(dtype, mem));
     if (!pos || !box || !total || n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "cos_angs: bad argument");
     if (!sub) ns = n;
     *total = 0;
     if (ns == 0) return WOL_OK;
+    const size_t esz = dtype == WOL_F64 ? sizeof(double) : sizeof(float);
     if (n == 0) {
-        if (num_angs) for (int i = 0; i < ns; ++i) num_angs[i] = 0.0;
+        if (num_angs) {
+            if (mem == WOL_MEM_HOST) memset(num_angs, 0, esz * (size_t)ns);
+            else HIP_TRY(hipMemsetAsync(num_angs, 0, esz * (size_t)ns, c->stream));
+        }
         return WOL_OK;
     }
     ShellArgs sa;
-    WOL_TRY(shell_setup(c, pos, n, sub, ns, box, highcut, &sa));
+    WOL_TRY(shell_setup(c, RealSrc{pos, dtype, mem}, n, RealSrc{sub, dtype, mem}, ns, box, highcut, &sa));
     sa.lowsq = lowcut * lowcut;
     sa.highsq = highcut * highcut;
     // layout of `small`: count[ns] ints | off_nbr[ns] | off_ang[ns] | totals[2] (long long)
@@ -1269,39 +1363,48 @@ int wol_cos_angs(wol_ctx* c, const double* pos, int n, const double* sub, int ns
     hipLaunchKernelGGL(k_shell_offsets, dim3(1), dim3(1024), 0, c->stream, d_count, ns, d_offn, d_offa, d_tot);
     long long tot[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, c->stream));
-    std::vector<int> hcount;
-    if (num_angs) {
-        hcount.resize((size_t)ns);
-        HIP_TRY(hipMemcpyAsync(hcount.data(), d_count, sizeof(int) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+    if (num_angs) {   // k per water as a real, like the reference's np.zeros array (wp:233)
+        WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)ns));
+        hipLaunchKernelGGL(k_int_to_f64, grid, dim3(WOL_BLOCK), 0, c->stream, d_count, c->qbuf.as<double>(), (int64_t)ns);
+        WOL_TRY(deliver_f64(c, c->qbuf.as<double>(), num_angs, (size_t)ns, dtype, mem, 0));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (num_angs) for (int i = 0; i < ns; ++i) num_angs[i] = (double)hcount[(size_t)i];
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the totals size the second call's buffer: a host value either way
     *total = (int64_t)tot[1];
     if (!ang || tot[1] == 0) return WOL_OK;
     WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)std::max<long long>(tot[0], 1)));
     WOL_TRY(c->out_stage.ensure(sizeof(double) * (size_t)tot[1]));
     hipLaunchKernelGGL(k_cos_angs_fill, grid, dim3(WOL_BLOCK), 0, c->stream, sa, d_offn, d_offa,
                        c->slow_list.as<unsigned long long>(), c->out_stage.as<double>());
-    HIP_TRY(hipMemcpyAsync(ang, c->out_stage.p, sizeof(double) * (size_t)tot[1], hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    WOL_TRY(deliver_f64(c, c->out_stage.as<double>(), ang, (size_t)tot[1], dtype, mem, 1));
+    if (mem == WOL_MEM_HOST) HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     return WOL_OK;
 }
 
-int wol_lsi_frame(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
-                  double lowcut, double highcut, double* lsi_full, double* num_lsi, int64_t* nvalid) {
+int wol_cos_angs(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+                 double lowcut, double highcut, double* ang, double* num_angs, int64_t* total) {
+    return wol_cos_angs_t(c, pos, n, sub, ns, box, lowcut, highcut, ang, num_angs, total, WOL_F64, WOL_MEM_HOST);
+}
+
+int wol_lsi_frame_t(wol_ctx* c, const void* pos, int n, const void* sub, int ns, const double* box,
+                    double lowcut, double highcut, void* lsi_full, void* num_lsi, int64_t* nvalid, int dtype, int mem) {
     WOL_TRY(check_ctx(c));
+    WOL_TRY(check_real(dtype, mem));
     if (!pos || !box || !lsi_full || n < 0 || ns < 0) return fail(WOL_ERR_INVALID, "lsi_frame: bad argument");
     if (!sub) ns = n;
     if (nvalid) *nvalid = 0;
     if (ns == 0) return WOL_OK;
     if (n == 0) {
-        for (int i = 0; i < ns; ++i) { lsi_full[i] = NAN; if (num_lsi) num_lsi[i] = 0.0; }
+        if (mem != WOL_MEM_HOST) return fail(WOL_ERR_INVALID, "lsi_frame: n == 0 with device buffers is not supported");
+        for (int i = 0; i < ns; ++i) {
+            if (dtype == WOL_F64) { static_cast<double*>(lsi_full)[i] = NAN; if (num_lsi) static_cast<double*>(num_lsi)[i] = 0.0; }
+            else { static_cast<float*>(lsi_full)[i] = NAN; if (num_lsi) static_cast<float*>(num_lsi)[i] = 0.f; }
+        }
         return WOL_OK;
     }
     const double high2 = highcut + 3.7;  // water_properties.py:276,281
     ShellArgs sa;
-    WOL_TRY(shell_setup(c, pos, n, sub, ns, box, high2, &sa));
+    WOL_TRY(shell_setup(c, RealSrc{pos, dtype, mem}, n, RealSrc{sub, dtype, mem}, ns, box, high2, &sa));
     sa.lowsq = lowcut * lowcut;
     sa.highsq = highcut * highcut;
     WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)WOL_LSI_CAP * (size_t)ns));
@@ -1312,21 +1415,24 @@ int wol_lsi_frame(wol_ctx* c, const double* pos, int n, const double* sub, int n
     double* d_num = d_lsi + ns;
     hipLaunchKernelGGL(k_lsi, dim3((ns + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream, sa,
                        high2 * high2, c->qbuf.as<double>(), d_lsi, d_num, c->slow_count.as<int>());
-    std::vector<double> hnum((size_t)ns);
+    std::vector<double> hlsi((size_t)ns);   // the count of valid entries (len(lsiVals), wp:308) is a host value
     int over = 0;
-    HIP_TRY(hipMemcpyAsync(lsi_full, d_lsi, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(hnum.data(), d_num, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
+    WOL_TRY(deliver_f64(c, d_lsi, lsi_full, (size_t)ns, dtype, mem, 0));
+    WOL_TRY(deliver_f64(c, d_num, num_lsi, (size_t)ns, dtype, mem, 1));
+    HIP_TRY(hipMemcpyAsync(hlsi.data(), d_lsi, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&over, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
     if (over) return fail(WOL_ERR_INVALID, "lsi_frame: a water has more than %d neighbours inside highcut", WOL_LSI_CAP - 2);
     int64_t nv = 0;
-    for (int i = 0; i < ns; ++i) {
-        if (num_lsi) num_lsi[i] = hnum[(size_t)i];
-        nv += (lsi_full[i] == lsi_full[i]) ? 1 : 0;
-    }
+    for (int i = 0; i < ns; ++i) nv += (hlsi[(size_t)i] == hlsi[(size_t)i]) ? 1 : 0;
     if (nvalid) *nvalid = nv;
     return WOL_OK;
+}
+
+int wol_lsi_frame(wol_ctx* c, const double* pos, int n, const double* sub, int ns, const double* box,
+                  double lowcut, double highcut, double* lsi_full, double* num_lsi, int64_t* nvalid) {
+    return wol_lsi_frame_t(c, pos, n, sub, ns, box, lowcut, highcut, lsi_full, num_lsi, nvalid, WOL_F64, WOL_MEM_HOST);
 }
 
 // ---- Willard-Chandler density field ---------------------------------------
@@ -1615,6 +1721,217 @@ int wol_q_traj_f32(wol_ctx* c, const float* frames, int64_t atom_stride, int64_t
                    int qbins, int64_t* dhist, int dbins, double dbinwidth, float* q_out, int mem) {
     return q_traj_impl<float>(c, frames, atom_stride, frame_stride, T, n, boxes, lowcut, highcut, mean, var,
                               qhist, qbins, dhist, dbins, dbinwidth, q_out, mem);
+}
+
+}  // extern "C"
+
+// ---- multi-GPU: frame shards + the path's one exchange step -----------------------------
+// RCCL is bound at run time: whichever librccl.so.1 the process already maps (PyTorch-ROCm ships its own copy, which
+// must be the one used next to torch) or, failing that, the system's.
+struct wol_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    bool own = false;
+};
+
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+    if (g_rccl.handle) return WOL_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(WOL_ERR_HIP, "RCCL not found: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather)
+        return fail(WOL_ERR_HIP, "RCCL library lacks an entry point");
+    g_rccl = a;
+    return WOL_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess)                                                                           \
+            return fail(WOL_ERR_HIP, "%s: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+template <typename T>
+int q_traj_sharded_impl(wol_ctx* c, wol_comm* comm, const T* frames, int64_t atom_stride, int64_t frame_stride, int T_local,
+                        int T_total, int n, const double* boxes, double low, double high, double* mean, double* var,
+                        int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, T* q_out, int mem) {
+    WOL_TRY(check_ctx(c));
+    if (!comm) return fail(WOL_ERR_INVALID, "q_traj_sharded: communicator must not be NULL");
+    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    int t0 = 0, t1 = 0;
+    WOL_TRY(wol_shard_bounds(T_total, comm->rank, comm->world, &t0, &t1));
+    if (T_local != t1 - t0)
+        return fail(WOL_ERR_INVALID, "q_traj_sharded: rank %d of %d owns frames [%d, %d) of %d, got %d frames", comm->rank,
+                    comm->world, t0, t1, T_total, T_local);
+    if (qhist && qbins <= 0) return fail(WOL_ERR_INVALID, "qbins must be > 0");
+    if (dhist && (dbins <= 0 || !(dbinwidth > 0.0))) return fail(WOL_ERR_INVALID, "dbins/dbinwidth must be > 0");
+    const bool host = (mem == WOL_MEM_HOST);
+    const int W = comm->world;
+    const int per = (T_total + W - 1) / W;            // frames per rank, padded: shards differ by at most one frame
+    const int nh = (qhist ? qbins : 0) + (dhist ? dbins : 0);
+    // exchange buffer (device): hist[nh] uint64 | mine[per][2] doubles | all[W][per][2] doubles
+    const size_t o_mine = sizeof(unsigned long long) * (size_t)std::max(nh, 1);
+    const size_t o_all = o_mine + sizeof(double) * 2 * (size_t)per;
+    WOL_TRY(c->xchg.ensure(o_all + sizeof(double) * 2 * (size_t)per * W));
+    char* xb = c->xchg.as<char>();
+    unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(xb);
+    double* d_mine = reinterpret_cast<double*>(xb + o_mine);
+    double* d_all = reinterpret_cast<double*>(xb + o_all);
+    HIP_TRY(hipMemsetAsync(xb, 0, o_all, c->stream));
+    // ---- this rank's frames: the local pipeline, integer histograms and the per-frame series left on the device ----
+    if (T_local > 0) {
+        if (host) {
+            std::vector<int64_t> hq((size_t)std::max(qbins, 1), 0), hd((size_t)std::max(dbins, 1), 0);
+            std::vector<double> hm((size_t)T_local), hv((size_t)T_local);
+            WOL_TRY((q_traj_impl<T>(c, frames, atom_stride, frame_stride, T_local, n, boxes, low, high, hm.data(), hv.data(),
+                                    qhist ? hq.data() : nullptr, qbins, dhist ? hd.data() : nullptr, dbins, dbinwidth, q_out, mem)));
+            std::vector<double> mv(2 * (size_t)per, 0.0);
+            for (int t = 0; t < T_local; ++t) { mv[2 * (size_t)t] = hm[(size_t)t]; mv[2 * (size_t)t + 1] = hv[(size_t)t]; }
+            if (qhist) HIP_TRY(hipMemcpyAsync(d_hist, hq.data(), sizeof(int64_t) * (size_t)qbins, hipMemcpyHostToDevice, c->stream));
+            if (dhist) HIP_TRY(hipMemcpyAsync(d_hist + (qhist ? qbins : 0), hd.data(), sizeof(int64_t) * (size_t)dbins, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_mine, mv.data(), sizeof(double) * mv.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors above go out of scope
+        } else {
+            // mean / var land in a scratch pair of arrays, then interleave into (mean, var) rows
+            WOL_TRY(c->cvt_out[3].ensure(sizeof(double) * 2 * (size_t)T_local));
+            double* sm = c->cvt_out[3].as<double>();
+            WOL_TRY((q_traj_impl<T>(c, frames, atom_stride, frame_stride, T_local, n, boxes, low, high, sm, sm + T_local,
+                                    qhist ? reinterpret_cast<int64_t*>(d_hist) : nullptr, qbins,
+                                    dhist ? reinterpret_cast<int64_t*>(d_hist + (qhist ? qbins : 0)) : nullptr, dbins, dbinwidth,
+                                    q_out, mem)));
+            HIP_TRY(hipMemcpy2DAsync(d_mine, 2 * sizeof(double), sm, sizeof(double), sizeof(double), (size_t)T_local, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipMemcpy2DAsync(d_mine + 1, 2 * sizeof(double), sm + T_local, sizeof(double), sizeof(double), (size_t)T_local, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    // ---- the exchange step: integer sums (order-independent, so the result is the one-GPU result bit for bit) and
+    //      the gathered per-frame series; KB-sized, latency-bound ----
+    if (nh > 0) NCCL_TRY(g_rccl.AllReduce(d_hist, d_hist, (size_t)nh, ncclUint64, ncclSum, comm->comm, c->stream));
+    if (mean || var) NCCL_TRY(g_rccl.AllGather(d_mine, d_all, 2 * (size_t)per, ncclFloat64, comm->comm, c->stream));
+    // ---- results to the caller: histograms ACCUMULATE into its arrays (as wol_q_traj), series in frame order ----
+    if (host) {
+        std::vector<unsigned long long> hh((size_t)std::max(nh, 1));
+        std::vector<double> all(2 * (size_t)per * W);
+        if (nh > 0) HIP_TRY(hipMemcpyAsync(hh.data(), d_hist, sizeof(unsigned long long) * (size_t)nh, hipMemcpyDeviceToHost, c->stream));
+        if (mean || var) HIP_TRY(hipMemcpyAsync(all.data(), d_all, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (qhist) for (int k = 0; k < qbins; ++k) qhist[k] += (int64_t)hh[(size_t)k];
+        if (dhist) for (int k = 0; k < dbins; ++k) dhist[k] += (int64_t)hh[(size_t)(qhist ? qbins : 0) + k];
+        for (int r = 0; r < W && (mean || var); ++r) {
+            int a = 0, b = 0;
+            (void)wol_shard_bounds(T_total, r, W, &a, &b);
+            for (int t = a; t < b; ++t) {
+                if (mean) mean[t] = all[2 * ((size_t)r * per + (t - a))];
+                if (var) var[t] = all[2 * ((size_t)r * per + (t - a)) + 1];
+            }
+        }
+    } else {
+        if (qhist) hipLaunchKernelGGL(k_add_u64, dim3((qbins + 255) / 256), dim3(256), 0, c->stream, d_hist,
+                                      reinterpret_cast<unsigned long long*>(qhist), qbins);
+        if (dhist) hipLaunchKernelGGL(k_add_u64, dim3((dbins + 255) / 256), dim3(256), 0, c->stream, d_hist + (qhist ? qbins : 0),
+                                      reinterpret_cast<unsigned long long*>(dhist), dbins);
+        for (int r = 0; r < W && (mean || var); ++r) {
+            int a = 0, b = 0;
+            (void)wol_shard_bounds(T_total, r, W, &a, &b);
+            if (b == a) continue;
+            const double* src = d_all + 2 * (size_t)r * per;
+            if (mean) HIP_TRY(hipMemcpy2DAsync(mean + a, sizeof(double), src, 2 * sizeof(double), sizeof(double), (size_t)(b - a), hipMemcpyDeviceToDevice, c->stream));
+            if (var) HIP_TRY(hipMemcpy2DAsync(var + a, sizeof(double), src + 1, 2 * sizeof(double), sizeof(double), (size_t)(b - a), hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int wol_shard_bounds(int T_total, int rank, int world, int* t0, int* t1) {
+    if (!t0 || !t1 || T_total < 0 || world < 1 || rank < 0 || rank >= world) return fail(WOL_ERR_INVALID, "shard_bounds: bad argument");
+    *t0 = (int)(((int64_t)rank * T_total) / world);
+    *t1 = (int)(((int64_t)(rank + 1) * T_total) / world);
+    return WOL_OK;
+}
+
+int wol_comm_unique_id(void* id128) {
+    if (!id128) return fail(WOL_ERR_INVALID, "unique id buffer must not be NULL");
+    WOL_TRY(rccl_load());
+    ncclUniqueId id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof id);
+    return WOL_OK;
+}
+
+int wol_comm_init(wol_ctx* c, const void* id128, int rank, int world, wol_comm** out) {
+    WOL_TRY(check_ctx(c));
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return fail(WOL_ERR_INVALID, "comm_init: bad argument");
+    *out = nullptr;
+    WOL_TRY(rccl_load());
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    ncclComm_t nc = nullptr;
+    NCCL_TRY(g_rccl.CommInitRank(&nc, world, id, rank));
+    wol_comm* m = new (std::nothrow) wol_comm();
+    if (!m) { (void)g_rccl.CommDestroy(nc); return fail(WOL_ERR_NOMEM, "out of host memory"); }
+    m->comm = nc; m->rank = rank; m->world = world; m->own = true;
+    *out = m;
+    return WOL_OK;
+}
+
+int wol_comm_adopt(void* nccl_comm, int rank, int world, wol_comm** out) {
+    if (!nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return fail(WOL_ERR_INVALID, "comm_adopt: bad argument");
+    *out = nullptr;
+    WOL_TRY(rccl_load());
+    wol_comm* m = new (std::nothrow) wol_comm();
+    if (!m) return fail(WOL_ERR_NOMEM, "out of host memory");
+    m->comm = static_cast<ncclComm_t>(nccl_comm); m->rank = rank; m->world = world; m->own = false;
+    *out = m;
+    return WOL_OK;
+}
+
+int wol_comm_destroy(wol_comm* m) {
+    if (!m) return WOL_OK;
+    if (m->own && m->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm);
+    delete m;
+    return WOL_OK;
+}
+
+int wol_q_traj_sharded(wol_ctx* c, wol_comm* comm, const double* frames, int64_t atom_stride, int64_t frame_stride,
+                       int T_local, int T_total, int n, const double* boxes, double lowcut, double highcut, double* mean,
+                       double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, double* q_out,
+                       int mem) {
+    return q_traj_sharded_impl<double>(c, comm, frames, atom_stride, frame_stride, T_local, T_total, n, boxes, lowcut, highcut,
+                                       mean, var, qhist, qbins, dhist, dbins, dbinwidth, q_out, mem);
+}
+
+int wol_q_traj_sharded_f32(wol_ctx* c, wol_comm* comm, const float* frames, int64_t atom_stride, int64_t frame_stride,
+                           int T_local, int T_total, int n, const double* boxes, double lowcut, double highcut, double* mean,
+                           double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, float* q_out,
+                           int mem) {
+    return q_traj_sharded_impl<float>(c, comm, frames, atom_stride, frame_stride, T_local, T_total, n, boxes, lowcut, highcut,
+                                      mean, var, qhist, qbins, dhist, dbins, dbinwidth, q_out, mem);
 }
 
 }  // extern "C"

@@ -145,3 +145,53 @@ def tet_order_traj_sharded(frames_local, boxes_local, T_total, frame_offset, gro
     local = tet_order_traj(frames_local, boxes_local, **kw)
     local.frame_offset = frame_offset
     return reduce_traj_result(local, T_total, group)
+
+
+def tet_order_traj_sharded_rccl(frames_local, boxes_local, T_total, comm, lowCut=0.0, highCut=10.0, len_wat=1, qbins=QBINS,
+                                dbins=DBINS, dbinwidth=DBINWIDTH, want_q=False, want_dhist=True):
+    """The same job through the library's own multi-GPU entry (include/wol.h: wol_q_traj_sharded): this rank's block of
+    frames (wol_shard_bounds) goes through the one-GPU pipeline and the exchange step runs inside the library on RCCL.
+    ``comm`` is a _lib.Comm; frames may be host numpy arrays or torch CUDA tensors on the communicator's device.
+    Returns the job-wide TrajResult (mean / var of ALL T_total frames, reduced histograms) on every rank; q is local."""
+    boxes_local = np.ascontiguousarray(np.asarray(boxes_local, dtype=np.float64).reshape(-1, 3))
+    ctx = comm.ctx
+    dev = _is_torch(frames_local)
+    if dev:
+        import torch
+        frames = frames_local.contiguous()
+        if not frames.is_cuda or frames.dtype not in (torch.float64, torch.float32) or frames.dim() != 3 or frames.shape[2] != 3:
+            raise ValueError("frames must be a float64/float32 CUDA tensor of shape (T, natoms, 3)")
+        f32 = frames.dtype == torch.float32
+    else:
+        frames = np.asarray(frames_local)
+        if frames.dtype != np.float32:
+            frames = np.asarray(frames, dtype=np.float64)
+        frames = np.ascontiguousarray(frames)
+        if frames.ndim != 3 or frames.shape[2] != 3:
+            raise ValueError("frames must have shape (T, natoms, 3)")
+        f32 = frames.dtype == np.float32
+    T, natoms, _ = frames.shape
+    _check_shapes(T, natoms, boxes_local, len_wat)
+    n = natoms // len_wat
+    fn = _lib.load().wol_q_traj_sharded_f32 if f32 else _lib.load().wol_q_traj_sharded
+    vp = C.c_void_p
+    if dev:
+        import torch
+        d = frames.device
+        ctx.set_stream(torch.cuda.current_stream(d).cuda_stream)
+        mean = torch.zeros(T_total, dtype=torch.float64, device=d); var = torch.zeros(T_total, dtype=torch.float64, device=d)
+        qh = torch.zeros(qbins, dtype=torch.int64, device=d)
+        dh = torch.zeros(dbins, dtype=torch.int64, device=d) if want_dhist else None
+        q = torch.empty((T, n), dtype=frames.dtype, device=d) if want_q else None
+        p = lambda t: vp(t.data_ptr()) if t is not None else None
+        _lib.check(fn(ctx.handle, comm.handle, p(frames), 3 * len_wat, 3 * natoms, T, T_total, n, _lib.ptr(boxes_local), float(lowCut),
+                      float(highCut), p(mean), p(var), p(qh), qbins, p(dh), dbins, float(dbinwidth), p(q), _lib.MEM_DEVICE))
+    else:
+        mean = np.zeros(T_total); var = np.zeros(T_total)
+        qh = np.zeros(qbins, dtype=np.int64)
+        dh = np.zeros(dbins, dtype=np.int64) if want_dhist else None
+        q = np.empty((T, n), dtype=frames.dtype) if want_q else None
+        _lib.check(fn(ctx.handle, comm.handle, _lib.ptr(frames), 3 * len_wat, 3 * natoms, T, T_total, n, _lib.ptr(boxes_local),
+                      float(lowCut), float(highCut), _lib.ptr(mean), _lib.ptr(var), _lib.ptr(qh), qbins, _lib.ptr(dh), dbins,
+                      float(dbinwidth), _lib.ptr(q), _lib.MEM_HOST))
+    return TrajResult(mean, var, qh, dh, q, comm.rank)

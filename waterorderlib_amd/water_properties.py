@@ -150,3 +150,74 @@ def HBondsGeneral(accPos, donPos, donHPos, boxL, accInds, donInds, donHInds, dis
     d = d - box * (np.sign(t) * np.floor(np.abs(t) + 0.5))     # anint: half away from zero (waterlib.f90:44)
     HBloc = 0.5 * ((a + d) + a)
     return NumHB, HBlist, HBloc
+
+
+# ---- device-resident / float32 forms (include/wol.h: wol_q_frame_t, wol_cos_angs_t, wol_lsi_frame_t) ------------
+# Same functions for callers whose coordinates already live in HBM as torch tensors (float64 or float32): nothing
+# crosses the host link, results are torch tensors on the same device with the input's dtype (arithmetic is fp64).
+def _dev_args(subPos, Pos):
+    import torch
+    if not (Pos.is_cuda and Pos.dim() == 2 and Pos.shape[1] == 3 and Pos.dtype in (torch.float64, torch.float32)):
+        raise ValueError("Pos must be a float64/float32 CUDA tensor of shape (n,3)")
+    Pos = Pos.contiguous()
+    same = subPos is Pos or subPos is None
+    if not same:
+        if subPos.dtype != Pos.dtype or subPos.device != Pos.device or subPos.dim() != 2 or subPos.shape[1] != 3:
+            raise ValueError("subPos must match Pos in dtype and device and have shape (ns,3)")
+        subPos = subPos.contiguous()
+    dt = _lib.F64 if Pos.dtype == torch.float64 else _lib.F32
+    ctx = _lib.default_context(Pos.device.index if Pos.device.index is not None else torch.cuda.current_device())
+    ctx.set_stream(torch.cuda.current_stream(Pos.device).cuda_stream)
+    return torch, Pos, (None if same else subPos), dt, ctx
+
+
+def getOrderParamq_dev(subPos, Pos, BoxDims, lowCut=0.0, highCut=10.0, full=False):
+    """getOrderParamq on torch CUDA tensors; returns q (and nn_idx int32, nn_dist, ang_deg with full=True) as tensors.
+    Asynchronous: the work is enqueued on torch's current stream."""
+    torch, Pos, sub, dt, ctx = _dev_args(subPos, Pos)
+    box = _lib.box3(BoxDims)
+    ns = len(Pos) if sub is None else len(sub)
+    q = torch.zeros(ns, dtype=Pos.dtype, device=Pos.device)
+    idx = torch.full((ns, 4), -1, dtype=torch.int32, device=Pos.device) if full else None
+    dist = torch.full((ns, 4), float("nan"), dtype=Pos.dtype, device=Pos.device) if full else None
+    ang = torch.full((ns, 6), float("nan"), dtype=Pos.dtype, device=Pos.device) if full else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    if ns and len(Pos):
+        _lib.check(_lib.load().wol_q_frame_t(ctx.handle, p(Pos), 3, len(Pos), p(sub), 3, ns, _lib.ptr(box), float(lowCut),
+                                             float(highCut), p(q), p(idx), p(dist), p(ang), dt, _lib.MEM_DEVICE))
+    return (q, idx, dist, ang) if full else q
+
+
+def getCosAngs_dev(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.413):
+    """getCosAngs on torch CUDA tensors -> (angVals, numAngs) tensors (the angle count is read back to size the output)."""
+    torch, Pos, sub, dt, ctx = _dev_args(subPos, Pos)
+    box = _lib.box3(BoxDims)
+    ns = len(Pos) if sub is None else len(sub)
+    num = torch.zeros(ns, dtype=Pos.dtype, device=Pos.device)
+    if ns == 0 or len(Pos) == 0:
+        return torch.zeros(0, dtype=Pos.dtype, device=Pos.device), num
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    total = C.c_int64(0)
+    L = _lib.load()
+    args = (ctx.handle, p(Pos), len(Pos), p(sub), ns, _lib.ptr(box), float(lowCut), float(highCut))
+    _lib.check(L.wol_cos_angs_t(*args, None, p(num), C.byref(total), dt, _lib.MEM_DEVICE))
+    ang = torch.empty(total.value, dtype=Pos.dtype, device=Pos.device)
+    if total.value:
+        _lib.check(L.wol_cos_angs_t(*args, p(ang), p(num), C.byref(total), dt, _lib.MEM_DEVICE))
+    return ang, num
+
+
+def getLSI_dev(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7):
+    """getLSI on torch CUDA tensors -> (lsiVals, numLSI) tensors; waters the reference skips are absent from lsiVals."""
+    torch, Pos, sub, dt, ctx = _dev_args(subPos, Pos)
+    box = _lib.box3(BoxDims)
+    ns = len(Pos) if sub is None else len(sub)
+    num = torch.zeros(ns, dtype=Pos.dtype, device=Pos.device)
+    if ns == 0 or len(Pos) == 0:
+        return torch.zeros(0, dtype=Pos.dtype, device=Pos.device), num
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    full = torch.empty(ns, dtype=Pos.dtype, device=Pos.device)
+    nvalid = C.c_int64(0)
+    _lib.check(_lib.load().wol_lsi_frame_t(ctx.handle, p(Pos), len(Pos), p(sub), ns, _lib.ptr(box), float(lowCut),
+                                           float(highCut), p(full), p(num), C.byref(nvalid), dt, _lib.MEM_DEVICE))
+    return full[~torch.isnan(full)], num
