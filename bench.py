@@ -94,6 +94,14 @@ def end_to_end(torch, engine, ctx, batch_dev, box, args):
         host[t, 0::lw] = o[t % F0]
     boxes = np.tile(box[None, :], (T, 1))
     out = {"frames": T, "atoms_per_water": lw, "frame_bytes": int(host[0].numel() * host.element_size())}
+    # what the link does on a plain linear copy of the same pinned bytes (the bound of any host-fed path)
+    scratch = torch.empty_like(host[:64], device=batch_dev.device)
+    scratch.copy_(host[:64], non_blocking=True); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    scratch.copy_(host[:64], non_blocking=True); torch.cuda.synchronize()
+    link = host[:64].numel() * host.element_size() / (time.perf_counter() - t0) / 1e9
+    del scratch
+    out["link_GBps_linear_copy"] = link
     for name, arr in (("pinned", host.numpy()), ("pageable", host.numpy().copy())):
         engine.tet_order_traj(arr[:64], boxes[:64], len_wat=lw, ctx=ctx)          # warm: staging buffers, page faults
         t0 = time.perf_counter()
@@ -101,7 +109,8 @@ def end_to_end(torch, engine, ctx, batch_dev, box, args):
         dt = time.perf_counter() - t0
         moved = ctx.counter("h2d_bytes")
         out[name] = {"frames_per_s": T / dt, "GBps_pcie": moved / dt / 1e9, "ms": 1e3 * dt,
-                     "bound_frames_per_s_at_this_rate": (moved / dt) / out["frame_bytes"],
+                     "link_bound_frames_per_s": link * 1e9 / out["frame_bytes"],
+                     "frac_of_link_bound": (T / dt) / (link * 1e9 / out["frame_bytes"]),
                      "mean_q": float(np.mean(res.mean))}
     # O-only host frames (what a caller that slices the oxygens out first would hand over): 4x fewer bytes per frame
     oo = o[:F0].repeat((T + F0 - 1) // F0, 1, 1)[:T].contiguous().pin_memory().numpy()
@@ -109,7 +118,8 @@ def end_to_end(torch, engine, ctx, batch_dev, box, args):
     t0 = time.perf_counter()
     engine.tet_order_traj(oo, boxes, ctx=ctx)
     dt = time.perf_counter() - t0
-    out["o_only_pinned"] = {"frames_per_s": T / dt, "GBps_pcie": ctx.counter("h2d_bytes") / dt / 1e9, "frame_bytes": int(oo[0].nbytes)}
+    out["o_only_pinned"] = {"frames_per_s": T / dt, "GBps_pcie": ctx.counter("h2d_bytes") / dt / 1e9, "frame_bytes": int(oo[0].nbytes),
+                            "frac_of_link_bound": (T / dt) / (link * 1e9 / oo[0].nbytes)}
     return out
 
 

@@ -34,4 +34,6 @@ def case_inputs(g):
 def oracle():
     import wol_oracle
     wol_oracle.lib()
+    # OpenMP would otherwise start one thread per core it can see; the GPU box shows far more cores than its CPU share
+    wol_oracle.set_threads(min(8, len(os.sched_getaffinity(0))))
     return wol_oracle

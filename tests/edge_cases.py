@@ -31,7 +31,11 @@ def frames_with_q_on_bin_edges(oracle, n=6000, n_targets=40, seed=5, qbins=500):
     from waterorderlib_amd import synth
     xyz, boxes = synth.water_frames(n, 1, seed=seed)
     pos, box = xyz[0].copy(), boxes[0]
+    oracle.set_threads(8)
     q, idx, dist, _ = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    # thousands of one-water oracle calls follow: one thread (an OpenMP team per call on a many-core host whose CPU
+    # share is small spends its time spinning)
+    oracle.set_threads(1)
     rng = np.random.default_rng(seed)
     order = rng.permutation(n)
     lo_frame, hi_frame = pos.copy(), pos.copy()
@@ -72,6 +76,7 @@ def frames_with_q_on_bin_edges(oracle, n=6000, n_targets=40, seed=5, qbins=500):
         lo_frame[nb, 0], hi_frame[nb, 0] = xa, xb
         used[near] = True
         targets.append(int(w)); edges.append(edge)
+    oracle.set_threads(8)
     return np.stack([lo_frame, hi_frame]), np.stack([box, box]), np.array(targets), np.array(edges)
 
 
@@ -81,6 +86,7 @@ def hbond_triples_on_the_cut(oracle, n=200, angcut=150.0, distcut=3.5, seed=9, b
     cut).  Pairs (i, j != i) are far apart (no bond)."""
     rng = np.random.default_rng(seed)
     box = np.asarray(box, dtype=np.float64)
+    oracle.set_threads(1)     # tens of thousands of one-pair oracle calls (see above)
     acc, don, hyd = [], [], []
     k = 0
     while len(acc) < 2 * n:
@@ -103,4 +109,5 @@ def hbond_triples_on_the_cut(oracle, n=200, angcut=150.0, distcut=3.5, seed=9, b
         for x in br:
             hh = h.copy(); hh[0] = x
             acc.append(a); don.append(d); hyd.append(hh)
+    oracle.set_threads(8)
     return np.array(acc), np.array(don), np.array(hyd), box

@@ -142,10 +142,13 @@ def test_config2_full_length_on_every_proposal_instantiation(oracle, variant):
     # the sampled frames on their own: integer histograms bit-exact against the oracle
     sub = engine.tet_order_traj(frames[list(sampled)].contiguous(), boxes[: len(sampled)], ctx=ctx)
     assert np.array_equal(sub.qhist.cpu().numpy(), qh)
-    # every variant gives the same integers (kept across the parametrised runs)
-    key = (res.qhist.cpu().numpy().tobytes(), res.dhist.cpu().numpy().tobytes(), res.mean.cpu().numpy().tobytes())
+    # every variant gives the same integers (kept across the parametrised runs); the per-frame means agree to rounding
+    # only: which waters take the exact kernel (full acos/cos chain) instead of the cosine form depends on the proposal
+    # kernel's error bound, and the two forms of q differ by ~1e-14
+    key = (res.qhist.cpu().numpy(), res.dhist.cpu().numpy(), res.mean.cpu().numpy())
     prev = test_config2_full_length_on_every_proposal_instantiation.__dict__.setdefault("seen", key)
-    assert prev == key
+    assert np.array_equal(prev[0], key[0]) and np.array_equal(prev[1], key[1])
+    np.testing.assert_allclose(prev[2], key[2], rtol=0, atol=1e-13)
     ctx.close()
 
 
