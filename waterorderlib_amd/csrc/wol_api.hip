@@ -95,7 +95,7 @@ struct wol_ctx {
     // search / finish kernels of the current batch on `stream` (the sort is memory-bound, the search
     // VALU-bound); events hand the sets back and forth
     struct SortSet {
-        DevBuf sorted, sorted32, cells, grids, level;
+        DevBuf sorted, sorted32, cells, grids, level, cnt4;
         hipEvent_t sorted_ev = nullptr;  // recorded on the sort stream when the set is filled
         hipEvent_t free_ev = nullptr;    // recorded on `stream` when its last reader is done
         bool used = false;
@@ -504,7 +504,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         c->grid_copy_pending = true;
         bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
         int tiles_max = 0;
-        const bool rows_kernel = c->search_rows && n <= (1 << WOL_SLOT_BITS);
+        // the row-merged proposal kernel needs the rows bin-sorted by k_sort_in_row: rows of up to WOL_L2_MAXNX cells
+        bool rows_kernel = c->search_rows && n <= (1 << WOL_SLOT_BITS);
+        for (int f = 0; f < F && rows_kernel; ++f)
+            if (gh[f].maxshell >= 0 && gh[f].nc[0] > WOL_L2_MAXNX) rows_kernel = false;
         for (int f = 0; f < F && use_fast; ++f) {
             if (gh[f].maxshell < 0) continue;
             if (!gh[f].fast_ok) use_fast = false;
@@ -535,6 +538,45 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             nrow_max = std::max(nrow_max, gh[f].nc[1] * gh[f].nc[2]);
         }
         const bool big_rows = nrow_max > WOL_L1_MAXROWS;
+        // second level of every sort: the rows (cell-sorted or merely bucketed) are sorted by fine x bin, with the bin
+        // populations per cell, into the final arrays.  The row-merged proposal kernel stages from rows in that order.
+        const bool in_row_stage = layer_sort || (use_fast && rows_kernel);
+        int nz_all = 0, nrow_all = 0, nb_cap = WOL_XSUB;
+        for (int f = 0; f < F; ++f) {
+            if (gh[f].maxshell < 0) continue;
+            nz_all = std::max(nz_all, gh[f].nc[2]);
+            nrow_all = std::max(nrow_all, gh[f].nc[1] * gh[f].nc[2]);
+            nb_cap = std::max(nb_cap, std::min(gh[f].nc[0], WOL_L2_MAXNX) * WOL_XSUB);
+        }
+        unsigned* cnt4 = nullptr;
+        if (use_fast && rows_kernel) {
+            WOL_TRY(S.cnt4.ensure(sizeof(unsigned) * (size_t)cell_total));
+            cnt4 = S.cnt4.as<unsigned>();
+        }
+        if (in_row_stage) WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
+        auto launch_in_row = [&](int ro_stride) {
+            const size_t lds = sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64);
+            if ((int64_t)n > 100 * (int64_t)std::max(nrow_all, 1))   // long rows (big boxes): four waters per lane
+                hipLaunchKernelGGL(k_sort_in_row<4>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<double4>(), s32, cnt4, nb_cap);
+            else
+                hipLaunchKernelGGL(k_sort_in_row<2>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<double4>(), s32, cnt4, nb_cap);
+        };
+        // (the cell-level sorts below write into the row buckets when the in-row stage follows them)
+        double4* cell_sorted_out = (in_row_stage && !layer_sort) ? c->sort_tmp.as<double4>() : S.sorted.as<double4>();
+        float4* cell_sorted_s32 = (in_row_stage && !layer_sort) ? nullptr : s32;
+        auto finish_cell_sort = [&]() -> int {
+            if (!in_row_stage || layer_sort) return WOL_OK;
+            const int ro_stride = nrow_all + 1;
+            WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
+            hipLaunchKernelGGL(k_rows_from_cells, dim3((nrow_all + WOL_BLOCK) / WOL_BLOCK, F), dim3(WOL_BLOCK), 0, ss,
+                               S.grids.as<FrameGrid>(), S.cells.as<int>(), c->layer_off.as<int>(), ro_stride);
+            launch_in_row(ro_stride);
+            return WOL_OK;
+        };
         int P = 1;
         if (layer_sort && (5 * F < 3 * c->num_cus || big_rows)) {   // fewer frames than ~0.6 blocks per CU: split them
             P = std::min(64, std::max(1, (2 * c->num_cus + F - 1) / F));          // about two blocks per CU
@@ -545,7 +587,6 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         if (layer_sort) {
             const int ro_stride = nrow_max + 1;
             WOL_TRY(c->layer_off.ensure(sizeof(int) * (size_t)F * ro_stride));
-            WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
             if (!c->sort_rows_lds_set) {
                 const int lds_a = (int)wol_sort_rows_lds(WOL_L1_MAXROWS, WOL_L1_CHUNK);
                 const int lds_b = (int)wol_sort_rows_lds(WOL_L1_MAXROWS_BIG, WOL_L1_CHUNK_BIG);
@@ -576,14 +617,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                                        wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
                                        c->sort_tmp.as<double4>(), nrow_max);
             }
-            if ((int64_t)n > 100 * (int64_t)nrow_max)   // long rows (big boxes): four waters per lane
-                hipLaunchKernelGGL(k_sort_in_row<4>, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
-                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
-                                   S.sorted.as<double4>(), s32);
-            else
-                hipLaunchKernelGGL(k_sort_in_row<2>, dim3(nz_max, F), dim3(WOL_BLOCK), 0, ss, S.grids.as<FrameGrid>(),
-                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
-                                   S.sorted.as<double4>(), s32);
+            launch_in_row(ro_stride);
         } else if (lds_sort) {
             if (sort_lds > c->sort_lds_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_frame_lds<T>),
@@ -592,7 +626,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             }
             hipLaunchKernelGGL(k_sort_frame_lds<T>, dim3(F), dim3(WOL_SORT_BLOCK), sort_lds, ss, fv,
                                S.grids.as<FrameGrid>(), S.cells.as<int>(), c->rank.as<int>(),
-                               S.sorted.as<double4>(), s32);
+                               cell_sorted_out, cell_sorted_s32);
+            WOL_TRY(finish_cell_sort());
         } else {
             HIP_TRY(hipMemsetAsync(S.cells.p, 0, sizeof(int) * (size_t)cell_total, ss));
             const dim3 gb((n + WOL_BLOCK - 1) / WOL_BLOCK, F);
@@ -600,7 +635,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                                S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>());
             WOL_TRY(launch_cell_scan(c, ss, S.grids.as<FrameGrid>(), S.cells.as<int>(), F, ncell_max));
             hipLaunchKernelGGL(k_scatter<T>, gb, dim3(WOL_BLOCK), 0, ss, fv, S.grids.as<FrameGrid>(),
-                               S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), S.sorted.as<double4>(), s32);
+                               S.cells.as<int>(), c->cellid.as<int>(), c->rank.as<int>(), cell_sorted_out, cell_sorted_s32);
+            WOL_TRY(finish_cell_sort());
         }
 
         if (pipe) {
@@ -648,6 +684,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             fa.prop_key = c->prop_key.as<int>();
             fa.stamps = nullptr;
             fa.rows = rows_kernel ? 1 : 0;
+            fa.cnt4 = cnt4;
 #ifdef WOL_PHASE_STAMPS
             WOL_TRY(c->stamps.ensure(sizeof(unsigned long long) * 8));
             fa.stamps = c->stamps.as<unsigned long long>();
@@ -1045,7 +1082,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     DevBuf* bufs[] = {&c->cellid, &c->rank, &c->qbuf, &c->in_stage,
                       &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps, &c->scan_tot};
     for (auto& S : c->sets) {
-        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release();
+        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release();
         if (S.sorted_ev) (void)hipEventDestroy(S.sorted_ev);
         if (S.free_ev) (void)hipEventDestroy(S.free_ev);
     }
@@ -1143,6 +1180,14 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
     }
     if (std::string(key) == "h2d_bytes") {   // bytes the last host-memory trajectory call sent over the link
         *value = (int64_t)c->last_h2d_bytes;
+        return WOL_OK;
+    }
+    if (std::string(key) == "tile_sx" || std::string(key) == "tile_ry" || std::string(key) == "tiles_per_frame") {
+        // geometry of the proposal kernel's tiles for frame 0 of the last batch at density level 0 (diagnostic)
+        const FrameGrid* g = c->grids_host.as<FrameGrid>();
+        *value = !g ? 0 : key[5] == 's' && key[4] == '_' ? (c->search_rows ? g->row_sx[0] : g->lev_sx[0])
+                          : key[5] == 'r' ? (c->search_rows ? g->row_ry[0] : g->lev_ry[0])
+                          : (c->search_rows ? g->row_ntiles[0] : g->lev_ntiles[0]);
         return WOL_OK;
     }
     if (std::string(key) == "rows_block") {  // k_search_rows instantiation of the last batch (threads per block)

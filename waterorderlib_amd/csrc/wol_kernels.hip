@@ -541,22 +541,40 @@ k_sort_rows_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const
 }
 
 // SLOTS waters per lane of a row are sorted through registers and LDS (rows of up to 64 * SLOTS waters; longer
-// rows take the direct form): 2 for the usual ~100-water rows, 4 for the long rows of big boxes
+// rows take the direct form): 2 for the usual ~100-water rows, 4 for the long rows of big boxes.
+//
+// The sort key is the FINE x bin (WOL_XSUB bins per cell, the bins of the proposal kernel's windows): every row of the
+// cell-sorted arrays is bin-sorted, each water's fp32 record carries its cell, sub-bin and rank inside the bin
+// (wol_pack_cell_tag), and cnt4[cell] holds the four sub-bin populations of the cell as bytes (saturating at 255; the
+// proposal kernel checks them against the cell population).  k_search_rows then places a staged water with table
+// look-ups only -- no counting pass, no atomics, one trip to memory per tile (wol_search_rows.hip).
+#ifndef WOL_XSUB
+#define WOL_XSUB 4            // fine x bins per cell
+#endif
+static_assert(WOL_XSUB == 4, "cnt4 packs the sub-bin populations of a cell into the four bytes of a word");
+
+// tag word of a sorted32 record (stored in .w as raw bits): cell number along x, sub-bin, rank inside the fine bin
+__device__ __forceinline__ float wol_pack_cell_tag(int cx, int sub, int rank) {
+    return __uint_as_float((unsigned)cx | ((unsigned)sub << 8) | ((unsigned)rank << 10));
+}
+
 template <int SLOTS>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
               const double4* __restrict__ tmp, int n, int* __restrict__ cell_start,
-              double4* __restrict__ sorted, float4* __restrict__ sorted32) {
-    __shared__ int cnt_all[(WOL_BLOCK / 64) * WOL_L2_MAXNX];
+              double4* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap) {
+    extern __shared__ int lds_row_bins[];   // per wave: cnt[nb_cap] (per fine bin: population, then first slot in the row) and
+                                            // cur[nb_cap] (long rows: running cursors); nb_cap >= nx * WOL_XSUB of every frame
     constexpr int WOL_L2_CAP = 64 * SLOTS;
-    __shared__ double4 st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];   // the row in cell order, written out linearly:
+    __shared__ double4 st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];   // the row in bin order, written out linearly:
     __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
     const int f = blockIdx.y, cz = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const FrameGrid& g = grids[f];
     const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
-    if (cz >= nz) return;
-    int* cnt = cnt_all + wave * WOL_L2_MAXNX;
+    if (cz >= nz || g.maxshell < 0 || nx * WOL_XSUB > nb_cap) return;   // (frames of the all-pairs path have no grid)
+    int* cnt = lds_row_bins + wave * 2 * nb_cap;
+    int* cur = cnt + nb_cap;
     double4* st64 = st64_all + wave * WOL_L2_CAP;
     float4* st32 = st32_all + wave * WOL_L2_CAP;
     const int* ro = row_off + (int64_t)f * ro_stride;
@@ -564,55 +582,96 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     double4* __restrict__ so = sorted + (int64_t)f * n;
     float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
     const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
+    // the proposal kernel's own expression for the fine bin of a staged coordinate (wol_search_rows.hip)
+    const float inv_wf = (float)WOL_XSUB / (float)(g.cw[0] * (double)g.scale);
+    const int nb = nx * WOL_XSUB;                    // fine bins of a row
+    const int cpl = (nx + 63) >> 6;                  // cells per lane in the scan (1 or 2: nx <= 128)
     for (int cy = wave; cy < ny; cy += WOL_BLOCK / 64) {  // one wave per row, no block-level barriers
         const int row = cz * ny + cy;
         const int b = ro[row], e = ro[row + 1];
         int* __restrict__ cs = cell_start + g.cell_base + (int64_t)row * nx;
-        for (int c = lane; c < nx; c += 64) cnt[c] = 0;
+        unsigned* __restrict__ c4 = cnt4 ? cnt4 + g.cell_base + (int64_t)row * nx : nullptr;
+        for (int c = lane; c < nb; c += 64) cnt[c] = 0;
         __builtin_amdgcn_wave_barrier();
-        if (e - b <= WOL_L2_CAP) {
-            // ---- the usual row: read once (two waters per lane stay in registers), rank = returning LDS atomic ----
-            double4 v[SLOTS];
-            float4 w[SLOTS];
-            int cxs[SLOTS], rank[SLOTS];
+        const bool fits = e - b <= WOL_L2_CAP;
+        double4 v[SLOTS];
+        float4 w[SLOTS];
+        int bins[SLOTS], rank[SLOTS];
+        if (fits) {
+            // ---- the usual row: read once (the waters stay in registers), rank = returning LDS atomic ----
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) {
                 const int i = b + lane + 64 * u;
-                cxs[u] = -1;
+                bins[u] = -1;
                 if (i < e) {
                     v[u] = in[i];
                     double ux = v[u].x * g.box.ib[0]; ux -= floor(ux);
                     double uy = v[u].y * g.box.ib[1]; uy -= floor(uy);
                     double uz = v[u].z * g.box.ib[2]; uz -= floor(uz);
                     int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);  // as wol_cell_coord
-                    cxs[u] = cx;
                     w[u].x = (float)((ux * (double)nx - (double)cx) * sx);
                     w[u].y = (float)((uy * (double)ny - (double)cy) * sy);
                     w[u].z = (float)((uz * (double)nz - (double)cz) * sz);
-                    w[u].w = (float)cx;  // cell number along x (k_search_rows builds tile coordinates from it)
-                    rank[u] = atomicAdd(&cnt[cx], 1);
+                    const int sub = min(WOL_XSUB - 1, (int)(w[u].x * inv_wf));
+                    bins[u] = cx * WOL_XSUB + sub;
+                    rank[u] = atomicAdd(&cnt[bins[u]], 1);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            {   // exclusive scan over the row's cells (nx <= 128: two per lane), cell_start of the row
-                const int c0 = 2 * lane, c1 = 2 * lane + 1;
-                const int v0 = c0 < nx ? cnt[c0] : 0, v1 = c1 < nx ? cnt[c1] : 0;
-                int inc = v0 + v1;
+        } else {
+            // ---- long rows: count first ----
+            for (int i = b + lane; i < e; i += 64) {
+                const double4 p = in[i];
+                double ux = p.x * g.box.ib[0]; ux -= floor(ux);
+                int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);
+                const float wx = (float)((ux * (double)nx - (double)cx) * sx);
+                const int bin = cx * WOL_XSUB + min(WOL_XSUB - 1, (int)(wx * inv_wf));
+                atomicAdd(&cnt[bin], 1);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {   // exclusive scan over the row's fine bins (a lane takes whole cells: four bins each), cell_start and the
+            // packed sub-bin populations of the row's cells
+            int c[2][WOL_XSUB], s = 0;
 #pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int t = __shfl_up(inc, off, 64);
-                    if (lane >= off) inc += t;
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int j = 0; j < WOL_XSUB; ++j) {
+                    const int cell = lane * cpl + k;
+                    c[k][j] = (k < cpl && cell < nx) ? cnt[cell * WOL_XSUB + j] : 0;
+                    s += c[k][j];
                 }
-                const int ex = inc - (v0 + v1);
-                if (c0 < nx) { cnt[c0] = ex; cs[c0] = b + ex; }
-                if (c1 < nx) { cnt[c1] = ex + v0; cs[c1] = b + ex + v0; }
+            int inc = s;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += t;
             }
+            int run = inc - s;
             __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int cell = lane * cpl + k;
+                if (k < cpl && cell < nx) {
+                    cs[cell] = b + run;
+                    if (c4) c4[cell] = (unsigned)min(c[k][0], 255) | ((unsigned)min(c[k][1], 255) << 8) |
+                                       ((unsigned)min(c[k][2], 255) << 16) | ((unsigned)min(c[k][3], 255) << 24);
+#pragma unroll
+                    for (int j = 0; j < WOL_XSUB; ++j) {
+                        cnt[cell * WOL_XSUB + j] = run;
+                        if (!fits) cur[cell * WOL_XSUB + j] = run;
+                        run += c[k][j];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (fits) {
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u)
-                if (cxs[u] >= 0) {
-                    const int d = cnt[cxs[u]] + rank[u];
+                if (bins[u] >= 0) {
+                    const int d = cnt[bins[u]] + rank[u];
                     st64[d] = v[u];
+                    w[u].w = wol_pack_cell_tag(bins[u] / WOL_XSUB, bins[u] % WOL_XSUB, rank[u]);
                     st32[d] = w[u];
                 }
             __builtin_amdgcn_wave_barrier();
@@ -623,44 +682,38 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             __builtin_amdgcn_wave_barrier();
             continue;
         }
-        // ---- long rows: count, scan, scatter straight into the final arrays ----
-        for (int i = b + lane; i < e; i += 64)
-            atomicAdd(&cnt[wol_cell_coord(in[i].x, g.box.ib[0], nx, nullptr)], 1);
-        __builtin_amdgcn_wave_barrier();
-        {
-            const int c0 = 2 * lane, c1 = 2 * lane + 1;
-            const int v0 = c0 < nx ? cnt[c0] : 0, v1 = c1 < nx ? cnt[c1] : 0;
-            int inc = v0 + v1;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += t;
-            }
-            const int ex = b + inc - (v0 + v1);
-            if (c0 < nx) { cnt[c0] = ex; cs[c0] = ex; }
-            if (c1 < nx) { cnt[c1] = ex + v0; cs[c1] = ex + v0; }
-        }
-        __builtin_amdgcn_wave_barrier();
+        // ---- long rows: scatter straight into the final arrays ----
         for (int i = b + lane; i < e; i += 64) {
-            const double4 v = in[i];
-            double ux = v.x * g.box.ib[0]; ux -= floor(ux);
-            double uy = v.y * g.box.ib[1]; uy -= floor(uy);
-            double uz = v.z * g.box.ib[2]; uz -= floor(uz);
+            const double4 p = in[i];
+            double ux = p.x * g.box.ib[0]; ux -= floor(ux);
+            double uy = p.y * g.box.ib[1]; uy -= floor(uy);
+            double uz = p.z * g.box.ib[2]; uz -= floor(uz);
             int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);  // as wol_cell_coord
-            const int dst = atomicAdd(&cnt[cx], 1);
-            so[dst] = v;
+            float4 q;
+            q.x = (float)((ux * (double)nx - (double)cx) * sx);
+            q.y = (float)((uy * (double)ny - (double)cy) * sy);
+            q.z = (float)((uz * (double)nz - (double)cz) * sz);
+            const int sub = min(WOL_XSUB - 1, (int)(q.x * inv_wf));
+            const int bin = cx * WOL_XSUB + sub;
+            const int dst = atomicAdd(&cur[bin], 1);
+            so[b + dst] = p;
             if (so32) {
-                float4 w;
-                w.x = (float)((ux * (double)nx - (double)cx) * sx);
-                w.y = (float)((uy * (double)ny - (double)cy) * sy);
-                w.z = (float)((uz * (double)nz - (double)cz) * sz);
-                w.w = (float)cx;
-                so32[dst] = w;
+                q.w = wol_pack_cell_tag(cx, sub, dst - cnt[bin]);
+                so32[b + dst] = q;
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (cz == nz - 1 && threadIdx.x == 0) cell_start[g.cell_base + (int64_t)nz * ny * nx] = n;
+}
+
+// row offsets of cell-sorted frames: lets the in-row sort above run behind the other (cell-level) sorts too
+__global__ void __launch_bounds__(WOL_BLOCK)
+k_rows_from_cells(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start, int* __restrict__ row_off, int ro_stride) {
+    const FrameGrid& g = grids[blockIdx.y];
+    const int nrow = g.nc[1] * g.nc[2];
+    const int r = blockIdx.x * WOL_BLOCK + threadIdx.x;
+    if (r <= nrow) row_off[(int64_t)blockIdx.y * ro_stride + r] = cell_start[g.cell_base + (int64_t)r * g.nc[0]];
 }
 
 // =============================================================================================

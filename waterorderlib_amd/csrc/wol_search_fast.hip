@@ -80,6 +80,7 @@ struct FastArgs {
     int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
     unsigned long long* stamps;  // diagnostic builds only
     int rows;               // 1: proposals come from k_search_rows (x reach counted in fine bins, its own eps)
+    const unsigned* cnt4;   // per cell: populations of its four fine x bins as bytes (k_sort_in_row); k_search_rows only
 };
 
 // sorted insert of `key` into k0 <= k1 <= ... <= k4 (the largest falls off): new k_i is the median of

@@ -41,6 +41,7 @@
 #define WOL_ROWS_BINW 704      // 32-bit words of bin counters: sum over the triples of ceil((bins + 1) / 2)
 #define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
 #define WOL_ROWS_TARGET(block) (((block) * 97) / 100)
+#define WOL_ROWS_CSCALE 0.0009765625f   // 2^-10
 #ifndef WOL_ROWS_WPS
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
 #endif
@@ -66,19 +67,27 @@ __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));  // row_bcast:15
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));  // row_bcast:31
     const int T = __builtin_amdgcn_readlane(m, 63);
+    // Issue cost on gfx950 (tools/valu_probe.hip, profiles/r02_valu_issue_rates.txt): min / max / med3, shifts, compares,
+    // selects and the packed fp32 forms hold a SIMD for 4 cycles per wave64 instruction, plain fp32 add / mul / fma and
+    // integer add / and for 2.  So: lanes past their window are masked off (one v_cmp feeding EXEC) instead of being
+    // redirected to a dummy pair (v_cmp + v_cndmask), and the squared distance is saturated by the CLAMP modifier of its
+    // last fma -- coordinates are staged in units of sqrt(2^-20 key units), so d^2 comes out in [0, 1] -- followed by one
+    // packed fma that turns it into the fixed-point mantissa (d^2 * 2^20 + 2^23 - 1), instead of two v_min_u32.
+    (void)dummy_off; (void)tmaxbits;
     for (int t = 0; t < T; ++t, off += 16) {
-        const int o = (off < end) ? off : dummy_off;
-        const float4 a = *reinterpret_cast<const float4*>(rec_bytes + o);
-        const float4 b = *reinterpret_cast<const float4*>(rec_bytes + o + B_OFF);
-        const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
-        wol_f2 tt = __builtin_elementwise_fma(dx, dx, bias);
-        tt = __builtin_elementwise_fma(dy, dy, tt);
-        tt = __builtin_elementwise_fma(dz, dz, tt);
-        // id word = entry << 20 | slot: v_alignbit_b32 shifts the squared distance above the entry number
-        const unsigned key0 = __builtin_amdgcn_alignbit(min(__float_as_uint(tt.x), tmaxbits), __float_as_uint(b.z), WOL_SLOT_BITS);
-        const unsigned key1 = __builtin_amdgcn_alignbit(min(__float_as_uint(tt.y), tmaxbits), __float_as_uint(b.w), WOL_SLOT_BITS);
-        wol_top5_insert(key0, k0, k1, k2, k3, k4);
-        wol_top5_insert(key1, k0, k1, k2, k3, k4);
+        if (off < end) {
+            const float4 a = *reinterpret_cast<const float4*>(rec_bytes + off);
+            const float4 b = *reinterpret_cast<const float4*>(rec_bytes + off + B_OFF);
+            const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
+            wol_f2 u = dx * dx, uc, tt;
+            u = __builtin_elementwise_fma(dy, dy, u);
+            asm("v_pk_fma_f32 %0, %1, %1, %2 clamp" : "=v"(uc) : "v"(dz), "v"(u));            // min(d^2, 1)
+            tt = __builtin_elementwise_fma(uc, (wol_f2){1048576.0f, 1048576.0f}, bias);
+            const unsigned key0 = __builtin_amdgcn_alignbit(__float_as_uint(tt.x), __float_as_uint(b.z), WOL_SLOT_BITS);
+            const unsigned key1 = __builtin_amdgcn_alignbit(__float_as_uint(tt.y), __float_as_uint(b.w), WOL_SLOT_BITS);
+            wol_top5_insert(key0, k0, k1, k2, k3, k4);
+            wol_top5_insert(key1, k0, k1, k2, k3, k4);
+        }
     }
 }
 
@@ -86,8 +95,8 @@ template <int WOL_ROWS_BLOCK, int WOL_ROWS_CAPP>
 __global__ void __launch_bounds__(WOL_ROWS_BLOCK, WOL_ROWS_WPS)   // 6 waves per SIMD either way: 3 x 8 or 2 x 12 waves per CU
 k_search_rows(FastArgs a) {
     __shared__ float4 rec[2 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)];  // pair records: array A (x0,x1,y0,y1), then array B (z0,z1,id0,id1)
-    __shared__ unsigned char rkb[2 * WOL_ROWS_CAPP];             // staged water (row order) -> rank inside its bin
-    __shared__ unsigned bins[WOL_ROWS_BINW];                     // per triple: 16-bit counters, then exclusive starts
+    __shared__ unsigned bins[WOL_ROWS_BINW];                     // per triple: first entry of every fine bin (16-bit), the total last
+    __shared__ unsigned obins[WOL_ROWS_BINW];                    // per triple and cell: bytes = waters of the rows below in each sub-bin
     __shared__ int rsrc[WOL_ROWS_MAXROWS * 3];                   // staged row: first slot of its three pieces
     __shared__ unsigned short rcnt[WOL_ROWS_MAXROWS * 3];        // ... and their lengths
     __shared__ int rpre[WOL_ROWS_MAXROWS + 1];                   // staged waters before the row
@@ -143,13 +152,19 @@ k_search_rows(FastArgs a) {
         const int64_t frame_off = (int64_t)f * a.n;
         const float fx = (float)(g.cw[0] * (double)g.scale), fy = (float)(g.cw[1] * (double)g.scale);
         const float fz = (float)(g.cw[2] * (double)g.scale);
-        const float inv_wf = (float)WOL_XSUB / fx;
+        // the records hold coordinates in units of 2^-10 sqrt(key unit) (an exact power-of-two rescaling of the sorted
+        // fp32 copy): squared distances then come out as fractions of the key range and saturate through CLAMP
+        const float fxs = fx * WOL_ROWS_CSCALE, fys = fy * WOL_ROWS_CSCALE, fzs = fz * WOL_ROWS_CSCALE;
         const float xc = 0.5f * (float)(sxe + 2), yc = 0.5f * (float)(re + 2);
 
         __syncthreads();           // the previous tile is done with the LDS tables
         WOL_STAMP(0);
-        // ---- phase 0/1: counters to zero; one thread per staged row: its three pieces ----
-        for (int i = tid; i < ntrip * nbw; i += WOL_ROWS_BLOCK) bins[i] = 0u;
+        // ---- phase 1: tables.  Threads 0 .. nrows-1: the three pieces (left halo cell, the tile's cells, right halo cell)
+        //      of one staged row each, from cell_start.  The other waves, one per triple: the sub-bin populations of the
+        //      triple's cells (cnt4: four bytes per cell, written by the in-row sort) of its three z rows -> first entry of
+        //      every fine bin of the merged triple (bins[], 16-bit) and, per bin, how many waters of the rows below
+        //      precede a row's own (obins[]: bytes).  The rows are bin-sorted and every record carries its rank inside its
+        //      bin, so these tables place a staged water without any counting pass. ----
         if (tid == 0) s_flag = 0;
         if (tid < nrows) {
             const int t = (int)(((float)tid + 0.5f) * (1.0f / 3.0f)), dzk = tid - 3 * t;
@@ -163,6 +178,43 @@ k_search_rows(FastArgs a) {
             rcnt[3 * tid] = (unsigned short)min(el - sl, 65535);
             rcnt[3 * tid + 1] = (unsigned short)min(eb - sb, 65535);
             rcnt[3 * tid + 2] = (unsigned short)min(er - sr, 65535);
+        }
+        {
+            constexpr int W0 = (WOL_ROWS_MAXROWS + 63) / 64;     // waves the row table keeps busy
+            const int ncs = sxe + 2;                             // staged cells of a row (<= 63: one lane each)
+            for (int t = wave - W0; t >= 0 && t < ntrip; t += NW - W0) {
+                unsigned w0 = 0u, w1 = 0u, w2 = 0u;
+                if (lane < ncs) {
+                    const int gx = lane == 0 ? wol_wrap_cell(x0 - 1, nx) : lane == ncs - 1 ? wol_wrap_cell(x0 + sxe, nx) : x0 + lane - 1;
+                    const int gy = wol_wrap_cell(y0 + t - 1, ny);
+                    const unsigned* __restrict__ c4 = a.cnt4 + g.cell_base + gx;
+                    w0 = c4[(wol_wrap_cell(cz - 1, nz) * ny + gy) * nx];
+                    w1 = c4[(cz * ny + gy) * nx];
+                    w2 = c4[(wol_wrap_cell(cz + 1, nz) * ny + gy) * nx];
+                }
+                // byte-wise sums stay inside their bytes while every population is below 64; denser bins (and
+                // saturated counts) send the tile to the exact path
+                if ((w0 | w1 | w2) & 0xC0C0C0C0u) s_flag = 1;
+                const unsigned w01 = w0 + w1, wt = w01 + w2;
+                const int c0 = (int)(wt & 0xFFu), c1 = (int)((wt >> 8) & 0xFFu), c2 = (int)((wt >> 16) & 0xFFu), c3 = (int)(wt >> 24);
+                const int s = (c0 + c1) + (c2 + c3);
+                int inc = s;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int v = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += v;
+                }
+                const int run = inc - s;
+                unsigned* __restrict__ bt = bins + t * nbw;
+                unsigned* __restrict__ ob = obins + t * nbw;
+                if (lane < ncs) {
+                    bt[2 * lane] = (unsigned)run | ((unsigned)(run + c0) << 16);
+                    bt[2 * lane + 1] = (unsigned)(run + c0 + c1) | ((unsigned)(run + c0 + c1 + c2) << 16);
+                    ob[2 * lane] = w0;        // waters of the z-1 row in the bin: they precede the z row's
+                    ob[2 * lane + 1] = w01;   // ... and the z-1 and z rows' precede the z+1 row's
+                }
+                if (lane == ncs - 1) bt[2 * ncs] = (unsigned)inc;   // bin nb holds the total
+            }
         }
         __syncthreads();
         if (wave == 0) {           // staged waters before each row (nrows <= 96: two rounds of 64)
@@ -198,6 +250,8 @@ k_search_rows(FastArgs a) {
             if (lane < ntrip)
 #pragma unroll
                 for (int u = 0; u < 9; ++u) tot += (int)rcnt[9 * lane + u];
+            // the sub-bin populations must add up to the cell populations (they saturate at 255 per bin)
+            if (lane < ntrip && (int)(bins[lane * nbw + 2 * (sxe + 2)] & 0xFFFFu) != tot) s_flag = 1;
             const int len = (tot + 1) & ~1;
             int inc = len;
 #pragma unroll
@@ -217,89 +271,63 @@ k_search_rows(FastArgs a) {
             if (lane == ntrip - 1) tbase[ntrip] = inc;
         }
         __syncthreads();
-        const bool overflow0 = s_flag != 0;
-        WOL_STAMP(1);
-        // ---- phase 2 (row form): one wave per staged row: fine bin and rank (returning LDS atomic) of every
-        //      water, ranks parked in LDS; small register footprint (three blocks per CU) ----
-        if (!overflow0) {
-            for (int r = wave; r < nrows; r += NW) {
-                const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f));
-                const int c0 = rcnt[3 * r], c1 = rcnt[3 * r + 1], c2 = rcnt[3 * r + 2];
-                const int s0 = rsrc[3 * r], s1 = rsrc[3 * r + 1], s2 = rsrc[3 * r + 2];
-                const int cnt = c0 + c1 + c2, pre = rpre[r];
-                unsigned* __restrict__ bt = bins + t * nbw;
-                // piece offsets folded into one add per piece: src = i + d_piece (selects, no branches: the loads of a
-                // row's iterations must not wait for one another)
-                const int d0 = s0, d1 = s1 - c0, d2 = s2 - c0 - c1;
-                for (int i = lane; i < cnt; i += 64) {
-                    const bool p0 = i < c0, p2 = i >= c0 + c1;
-                    const int src = i + (p0 ? d0 : p2 ? d2 : d1);
-                    const float4 v = sp32[src];
-                    // (masks instead of selects: the compiler would otherwise fetch v.w in a second, conditional load)
-                    const int sc = (((int)v.w - x0 + 1) & ((p0 || p2) ? 0 : -1)) | (p2 ? sxe + 1 : 0);
-                    const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(v.x * inv_wf));
-                    const unsigned old = atomicAdd(&bt[bin >> 1], (bin & 1) ? 0x10000u : 1u);
-                    const unsigned rank = (bin & 1) ? (old >> 16) : (old & 0xFFFFu);
-                    if (rank > 255u) s_flag = 1;
-                    rkb[pre + i] = (unsigned char)rank;
-                }
-            }
-        }
-        __syncthreads();
-        WOL_STAMP(2);
-        // ---- phase 2b: counts -> starts inside every triple (a wave per triple, four bins per lane) ----
-        for (int t = wave; t < ntrip; t += NW) {
-            unsigned* __restrict__ bt = bins + t * nbw;
-            const bool mine = 2 * lane < nbw;      // this lane's two words (bins 4*lane .. 4*lane+3) exist
-            const unsigned w0 = mine ? bt[2 * lane] : 0u, w1 = (2 * lane + 1 < nbw) ? bt[2 * lane + 1] : 0u;
-            int c[4] = {(int)(w0 & 0xFFFFu), (int)(w0 >> 16), (int)(w1 & 0xFFFFu), (int)(w1 >> 16)};
-            int s = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { if (4 * lane + u >= nb) c[u] = 0; s += c[u]; }
-            int inc = s;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += v;
-            }
-            const int tot = __shfl(inc, 63, 64);
-            int run = inc - s, st[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { st[u] = (4 * lane + u < nb) ? run : tot; run += c[u]; }   // bin nb holds the total
-            if (mine) bt[2 * lane] = (unsigned)st[0] | ((unsigned)st[1] << 16);
-            if (2 * lane + 1 < nbw) bt[2 * lane + 1] = (unsigned)st[2] | ((unsigned)st[3] << 16);
-        }
-        __syncthreads();
         const bool overflow = s_flag != 0;
         const int total_e = tbase[ntrip];
-        WOL_STAMP(3);
+        WOL_STAMP(1);
         const int dummy_p = (total_e >> 1) + WOL_ROWS_PADP - 2;
-        // ---- phase 3: every water to its place (from the registers of phase 2) ----
+        // ---- phase 2: every water to its place, ONE pass: entry = first entry of the triple's bin + the waters of the rows
+        //      below in that bin + its rank inside the bin.  A wave takes whole rows; the fetch of the next 64 waters is in
+        //      flight while the current 64 are placed. ----
         if (!overflow) {
-            for (int r = wave; r < nrows; r += NW) {
+            const unsigned char* __restrict__ ob8 = reinterpret_cast<const unsigned char*>(obins);
+            int r = wave, i0 = 0;
+            int c0 = 0, c1 = 0, cnt = 0, d0 = 0, d1 = 0, d2 = 0;   // the current row's pieces (wave-uniform)
+#define WOL_ROW_PARAMS(rr)                                                                          \
+            do {                                                                                    \
+                c0 = rcnt[3 * (rr)]; c1 = rcnt[3 * (rr) + 1];                                       \
+                cnt = c0 + c1 + (int)rcnt[3 * (rr) + 2];                                            \
+                d0 = rsrc[3 * (rr)]; d1 = rsrc[3 * (rr) + 1] - c0; d2 = rsrc[3 * (rr) + 2] - c0 - c1; \
+            } while (0)
+            while (r < nrows) { WOL_ROW_PARAMS(r); if (cnt > 0) break; r += NW; }   // first non-empty row of this wave
+            float4 vn;
+            vn.x = vn.y = vn.z = vn.w = 0.f;
+            int srcn = lane + (lane < c0 ? d0 : lane >= c0 + c1 ? d2 : d1);
+            if (r < nrows && lane < cnt) vn = sp32[srcn];
+            while (r < nrows) {
+                // the current chunk of 64 waters
+                const float4 v = vn;
+                const int src = srcn, i = i0 + lane;
+                const int cc0 = c0, cc1 = c1, ccnt = cnt;
                 const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f)), dzk = r - 3 * t;
-                const int c0 = rcnt[3 * r], c1 = rcnt[3 * r + 1], c2 = rcnt[3 * r + 2];
-                const int s0 = rsrc[3 * r], s1 = rsrc[3 * r + 1], s2 = rsrc[3 * r + 2];
-                const int cnt = c0 + c1 + c2, pre = rpre[r];
-                const unsigned short* __restrict__ bt = bins16 + 2 * t * nbw;
-                const int tb = tbase[t];
-                const float offy = ((float)t - yc) * fy, offz = (float)(dzk - 1) * fz;
-                const int d0 = s0, d1 = s1 - c0, d2 = s2 - c0 - c1;
-                for (int i = lane; i < cnt; i += 64) {
-                    const bool p0 = i < c0, p2 = i >= c0 + c1;
-                    const int src = i + (p0 ? d0 : p2 ? d2 : d1);
-                    const float4 v = sp32[src];
-                    // (masks instead of selects: the compiler would otherwise fetch v.w in a second, conditional load)
-                    const int sc = (((int)v.w - x0 + 1) & ((p0 || p2) ? 0 : -1)) | (p2 ? sxe + 1 : 0);
-                    const int bin = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(v.x * inv_wf));
-                    const int e = tb + (int)bt[bin] + (int)rkb[pre + i];
+                // advance to the next chunk and start its fetch
+                i0 += 64;
+                if (i0 >= cnt) {
+                    i0 = 0;
+                    do { r += NW; if (r < nrows) WOL_ROW_PARAMS(r); } while (r < nrows && cnt == 0);
+                }
+                if (r < nrows) {
+                    const int in_ = i0 + lane;
+                    srcn = in_ + (in_ < c0 ? d0 : in_ >= c0 + c1 ? d2 : d1);
+                    if (in_ < cnt) vn = sp32[srcn];
+                }
+                // place the current chunk
+                if (i < ccnt) {
+                    const bool p0 = i < cc0, p2 = i >= cc0 + cc1;
+                    const unsigned tag = __float_as_uint(v.w);
+                    const int cx = (int)(tag & 0xFFu), sub = (int)((tag >> 8) & 3u), rank = (int)(tag >> 10);
+                    const int sc = p0 ? 0 : p2 ? sxe + 1 : cx - x0 + 1;
+                    const int bin = sc * WOL_XSUB + sub;
+                    const int below = dzk == 0 ? 0 : (int)ob8[(t * nbw + 2 * sc + (dzk - 1)) * 4 + sub];
+                    const int e = tbase[t] + (int)bins16[2 * t * nbw + bin] + below + rank;
                     const int o = (e >> 1) * 4 + (e & 1);
-                    recf[o] = ((float)sc - xc) * fx + v.x;
-                    recf[o + 2] = offy + v.y;
-                    recg[o] = offz + v.z;
+                    const float offy = ((float)t - yc) * fys, offz = (float)(dzk - 1) * fzs;
+                    recf[o] = __builtin_fmaf(v.x, WOL_ROWS_CSCALE, ((float)sc - xc) * fxs);
+                    recf[o + 2] = __builtin_fmaf(v.y, WOL_ROWS_CSCALE, offy);
+                    recg[o] = __builtin_fmaf(v.z, WOL_ROWS_CSCALE, offz);
                     recg[o + 2] = __uint_as_float(((unsigned)e << WOL_SLOT_BITS) | (unsigned)src);
                 }
             }
+#undef WOL_ROW_PARAMS
             if (tid < WOL_ROWS_PADP) {   // head-room pairs (incl. the dummy pair): nothing near
                 const int p = (total_e >> 1) + tid;
                 float4 far;
@@ -328,9 +356,11 @@ k_search_rows(FastArgs a) {
             int kd3 = -1;
             if (!overflow) {
                 const float4 me = sp32[self_slot];
-                const int sc = (int)me.w - x0 + 1;
-                const int b = sc * WOL_XSUB + min(WOL_XSUB - 1, (int)(me.x * inv_wf));
-                const float mx = ((float)sc - xc) * fx + me.x, my = ((float)(j + 1) - yc) * fy + me.y, mz = me.z;
+                const unsigned mtag = __float_as_uint(me.w);
+                const int sc = (int)(mtag & 0xFFu) - x0 + 1;
+                const int b = sc * WOL_XSUB + (int)((mtag >> 8) & 3u);
+                const float mx = __builtin_fmaf(me.x, WOL_ROWS_CSCALE, ((float)sc - xc) * fxs);
+                const float my = __builtin_fmaf(me.y, WOL_ROWS_CSCALE, ((float)(j + 1) - yc) * fys), mz = me.z * WOL_ROWS_CSCALE;
                 const wol_f2 xi = {mx, mx}, yi = {my, my}, zi = {mz, mz};
                 const unsigned tmaxbits = __float_as_uint(g.tmax);
                 unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
