@@ -128,19 +128,39 @@ k_search_rows(FastArgs a) {
         const FrameGrid& gg = a.grids[ff];
         return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.row_ntiles[a.level[ff]];
     };
+    // Per-frame constants stay in scalar registers from tile to tile (a block walks ~20 tiles of a frame before it
+    // moves on): re-reading the frame's grid and re-deriving them per tile, on the vector unit of every wave, was a
+    // sixth of the kernel's vector instructions.  Tile numbers are decoded with reciprocals (exact: operands < 2^22).
+#define WOL_SGPR_I(x) __builtin_amdgcn_readfirstlane((int)(x))
+#define WOL_SGPR_F(x) __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(x))))
+    int f_cur = -1;
+    int nx = 1, ny = 1, nz = 1, gsx = 1, gry = 1, gntx = 1, ntxy = 1, cell_base = 0, eps_units = 0;
+    float inv_ntxy = 1.f, inv_gntx = 1.f, fxs = 0.f, fys = 0.f, fzs = 0.f, eps_a = 0.f, eps_b = 0.f;
     int nt_f = tiles_of(f);
     for (;; tile += tstep) {
         while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
         if (f >= a.F) break;
-        const FrameGrid& g = a.grids[f];
-        const int lev = a.level[f];
-        const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
-        const int gsx = g.row_sx[lev], gry = g.row_ry[lev];
-        const int gntx = g.row_ntx[lev], gnty = g.row_nty[lev];
-        const int ntxy = gntx * gnty;
-        const int cz = (int)(((float)tile + 0.5f) / (float)ntxy);
+        if (f != f_cur) {
+            const FrameGrid& g = a.grids[f];
+            const int lev = a.level[f];
+            nx = WOL_SGPR_I(g.nc[0]); ny = WOL_SGPR_I(g.nc[1]); nz = WOL_SGPR_I(g.nc[2]);
+            gsx = WOL_SGPR_I(g.row_sx[lev]); gry = WOL_SGPR_I(g.row_ry[lev]);
+            gntx = WOL_SGPR_I(g.row_ntx[lev]);
+            ntxy = WOL_SGPR_I(gntx * (int)g.row_nty[lev]);
+            cell_base = WOL_SGPR_I(g.cell_base);    // (a batch's cell tables stay below 2^31 entries)
+            eps_units = WOL_SGPR_I(g.row_eps_units);
+            inv_ntxy = WOL_SGPR_F(1.0f / (float)ntxy); inv_gntx = WOL_SGPR_F(1.0f / (float)gntx);
+            // the records hold coordinates in units of 2^-10 sqrt(key unit) (an exact power-of-two rescaling of the
+            // sorted fp32 copy): squared distances then come out as fractions of the key range and saturate through CLAMP
+            fxs = WOL_SGPR_F((float)(g.cw[0] * (double)g.scale) * WOL_ROWS_CSCALE);
+            fys = WOL_SGPR_F((float)(g.cw[1] * (double)g.scale) * WOL_ROWS_CSCALE);
+            fzs = WOL_SGPR_F((float)(g.cw[2] * (double)g.scale) * WOL_ROWS_CSCALE);
+            eps_a = WOL_SGPR_F(g.row_eps_a); eps_b = WOL_SGPR_F(g.row_eps_b);
+            f_cur = f;
+        }
+        const int cz = (int)(((float)tile + 0.5f) * inv_ntxy);
         const int trem = tile - cz * ntxy;
-        const int ty = (int)(((float)trem + 0.5f) / (float)gntx);
+        const int ty = (int)(((float)trem + 0.5f) * inv_gntx);
         const int tx = trem - ty * gntx;
         const int x0 = tx * gsx, sxe = min(gsx, nx - x0);
         const int y0 = ty * gry, re = min(gry, ny - y0);
@@ -148,13 +168,8 @@ k_search_rows(FastArgs a) {
         const int nb = (sxe + 2) * WOL_XSUB, nbw = (nb + 2) >> 1;   // bins, words per triple (nb + 1 halves)
         const unsigned short* __restrict__ bins16 = reinterpret_cast<const unsigned short*>(bins);
         const float4* __restrict__ sp32 = a.sorted32 + (int64_t)f * a.n;
-        const int* __restrict__ cs = a.cell_start + g.cell_base;
+        const int* __restrict__ cs = a.cell_start + cell_base;
         const int64_t frame_off = (int64_t)f * a.n;
-        const float fx = (float)(g.cw[0] * (double)g.scale), fy = (float)(g.cw[1] * (double)g.scale);
-        const float fz = (float)(g.cw[2] * (double)g.scale);
-        // the records hold coordinates in units of 2^-10 sqrt(key unit) (an exact power-of-two rescaling of the sorted
-        // fp32 copy): squared distances then come out as fractions of the key range and saturate through CLAMP
-        const float fxs = fx * WOL_ROWS_CSCALE, fys = fy * WOL_ROWS_CSCALE, fzs = fz * WOL_ROWS_CSCALE;
         const float xc = 0.5f * (float)(sxe + 2), yc = 0.5f * (float)(re + 2);
 
         __syncthreads();           // the previous tile is done with the LDS tables
@@ -187,7 +202,7 @@ k_search_rows(FastArgs a) {
                 if (lane < ncs) {
                     const int gx = lane == 0 ? wol_wrap_cell(x0 - 1, nx) : lane == ncs - 1 ? wol_wrap_cell(x0 + sxe, nx) : x0 + lane - 1;
                     const int gy = wol_wrap_cell(y0 + t - 1, ny);
-                    const unsigned* __restrict__ c4 = a.cnt4 + g.cell_base + gx;
+                    const unsigned* __restrict__ c4 = a.cnt4 + cell_base + gx;
                     w0 = c4[(wol_wrap_cell(cz - 1, nz) * ny + gy) * nx];
                     w1 = c4[(cz * ny + gy) * nx];
                     w2 = c4[(wol_wrap_cell(cz + 1, nz) * ny + gy) * nx];
@@ -362,7 +377,7 @@ k_search_rows(FastArgs a) {
                 const float mx = __builtin_fmaf(me.x, WOL_ROWS_CSCALE, ((float)sc - xc) * fxs);
                 const float my = __builtin_fmaf(me.y, WOL_ROWS_CSCALE, ((float)(j + 1) - yc) * fys), mz = me.z * WOL_ROWS_CSCALE;
                 const wol_f2 xi = {mx, mx}, yi = {my, my}, zi = {mz, mz};
-                const unsigned tmaxbits = __float_as_uint(g.tmax);
+                const unsigned tmaxbits = 0u;
                 unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
                 // the three windows as (pairs << 16 | first pair); each lane sweeps its longest first: the loops' trip
                 // counts are wave maxima, and maxima of sorted lengths add up to less (38.3 instead of 40.5 pairs)
@@ -390,10 +405,10 @@ k_search_rows(FastArgs a) {
 #endif
                 }
                 const unsigned d3 = k3 >> WOL_ID_BITS, d4 = k4 >> WOL_ID_BITS;
-                const unsigned sat = (1u << (32 - WOL_ID_BITS)) - 1u - (unsigned)g.row_eps_units;
+                const unsigned sat = (1u << (32 - WOL_ID_BITS)) - 1u - (unsigned)eps_units;
                 // the proposal stands when the 5th key is separated from the 4th by more than both keys' fp32 error
                 // (bound evaluated at the 5th distance, the larger of the two)
-                const float eps4 = g.row_eps_a * __builtin_sqrtf((float)d4) + g.row_eps_b;
+                const float eps4 = eps_a * __builtin_sqrtf((float)d4) + eps_b;
                 if (k3 != 0xFFFFFFFFu && d3 < sat && (float)(d4 - d3) > 2.0f * eps4) {
                     const unsigned m = (1u << WOL_ID_BITS) - 1u, sm = (1u << WOL_SLOT_BITS) - 1u;
                     auto slot_of = [&](unsigned key) -> int {
