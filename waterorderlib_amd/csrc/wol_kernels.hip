@@ -325,13 +325,12 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
     const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
     const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
     double nx_[CH], ny_[CH], nz_[CH];
+    if (i_begin >= i_end) return;
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-        const int i = i_begin + u * WOL_SORT_BLOCK + tid;
-        if (i < i_end) {
-            const T* p = base + (int64_t)i * atom_stride;
-            nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
-        }
+    for (int u = 0; u < CH; ++u) {   // (clamped, unconditional loads: see wol_sort_rows_count)
+        const int i = min(i_begin + u * WOL_SORT_BLOCK + tid, i_end - 1);
+        const T* p = base + (int64_t)i * atom_stride;
+        nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
     }
     for (int c0 = i_begin; c0 < i_end; c0 += C) {
         const int cn = min(C, i_end - c0);
@@ -342,11 +341,9 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
         for (int u = 0; u < CH; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int i = c0 + C + u * WOL_SORT_BLOCK + tid;
-            if (i < i_end) {
-                const T* p = base + (int64_t)i * atom_stride;
-                nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
-            }
+            const int i = min(c0 + C + u * WOL_SORT_BLOCK + tid, i_end - 1);
+            const T* p = base + (int64_t)i * atom_stride;
+            nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -393,7 +390,11 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
             }
         __syncthreads();
         // (4) out, in staged order; the owners clear the chunk counters for the next round
-        for (int k = tid; k < cn; k += WOL_SORT_BLOCK) out[dest[k]] = stage[k];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {   // (a fixed number of stores per chunk: the wait for the next chunk's
+            const int k = tid + u * WOL_SORT_BLOCK;   //  coordinates, fetched before them, need not drain them)
+            if (k < cn) out[dest[k]] = stage[k];
+        }
         for (int k = sb; k < se; ++k) icnt[k] = 0;
         __syncthreads();
     }
@@ -410,10 +411,13 @@ __device__ __forceinline__ void wol_sort_rows_count(const T* __restrict__ base, 
     const int tid = threadIdx.x, ny = g.nc[1], nz = g.nc[2];
     for (int i0 = i_begin + tid; i0 < i_end; i0 += WOL_SORT_BLOCK * U) {
         double y[U], z[U];
+        // (loads are unconditional -- the index is clamped -- so the compiler issues all U before the first wait: behind
+        //  a per-element `if` it waited for every load on its own, one memory round trip after the other)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * WOL_SORT_BLOCK;
-            if (i < i_end) { const T* p = base + (int64_t)i * atom_stride; y[u] = (double)p[1]; z[u] = (double)p[2]; }
+            const int i = min(i0 + u * WOL_SORT_BLOCK, i_end - 1);
+            const T* p = base + (int64_t)i * atom_stride;
+            y[u] = (double)p[1]; z[u] = (double)p[2];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -593,18 +597,19 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         unsigned* __restrict__ c4 = cnt4 ? cnt4 + g.cell_base + (int64_t)row * nx : nullptr;
         for (int c = lane; c < nb; c += 64) cnt[c] = 0;
         __builtin_amdgcn_wave_barrier();
-        const bool fits = e - b <= WOL_L2_CAP;
+        const bool fits = e - b <= WOL_L2_CAP && e > b;
         double4 v[SLOTS];
         float4 w[SLOTS];
         int bins[SLOTS], rank[SLOTS];
         if (fits) {
             // ---- the usual row: read once (the waters stay in registers), rank = returning LDS atomic ----
 #pragma unroll
+            for (int u = 0; u < SLOTS; ++u) v[u] = in[min(b + lane + 64 * u, e - 1)];   // all in flight together (e > b here)
+#pragma unroll
             for (int u = 0; u < SLOTS; ++u) {
                 const int i = b + lane + 64 * u;
                 bins[u] = -1;
                 if (i < e) {
-                    v[u] = in[i];
                     double ux = v[u].x * g.box.ib[0]; ux -= floor(ux);
                     double uy = v[u].y * g.box.ib[1]; uy -= floor(uy);
                     double uz = v[u].z * g.box.ib[2]; uz -= floor(uz);
