@@ -115,7 +115,8 @@ struct wol_ctx {
     SortSet* last_set = nullptr;
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps, scan_tot;
     PinBuf grids_host;
-    DevBuf cvt_in, cvt_out[4], xchg;   // float <-> double conversion staging of the typed per-frame calls; exchange buffer of the sharded call
+    DevBuf cvt_in, cvt_out[4], xchg, stat_part;
+    int stat_slots = 0;   // slots per frame of stat_part in the last batch (0: unused)   // float <-> double conversion staging of the typed per-frame calls; exchange buffer of the sharded call
     // host-trajectory pipeline (wol_q_traj with WOL_MEM_HOST): two staging sets; the copy of batch k+1 runs on
     // copy_stream under batch k's kernels
     DevBuf host_stage[2];
@@ -439,6 +440,7 @@ template <typename T>
 int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
                 int64_t sub_stride, int ns, double low, double high, QOut out, bool allow_pipe = false) {
     const int n = fv.n;
+    c->stat_slots = 0;   // (set again below when the certification kernel keeps per-wave partial sums)
     if (F <= 0 || ns <= 0) return WOL_OK;
     const double lowsq = low * low, highsq = high * high;
     const size_t hist_lds = (size_t)((out.qhist ? out.qbins : 0) + (out.dhist ? out.dbins : 0)) * sizeof(int);
@@ -707,6 +709,18 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             if (lean) WOL_TRY(resident_grid(c, k_finish_fast<true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             else WOL_TRY(resident_grid(c, k_finish_fast<false>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             if (fa.xcd_affine) ggrid = std::max(8, (ggrid / 8) * 8);
+            fa.stat_part = nullptr; fa.stat_slots = 0;
+            c->stat_slots = 0;
+            if (lean && out.stat) {   // per-wave partial sums of the frame statistics (summed by k_stat_finalize)
+                const int slots = (fa.xcd_affine ? ggrid / 8 : ggrid) * (WOL_BLOCK / 64);
+                if ((size_t)slots * F * 32 <= ((size_t)256 << 20)) {
+                    WOL_TRY(c->stat_part.ensure(sizeof(long long) * 4 * (size_t)slots * F));
+                    HIP_TRY(hipMemsetAsync(c->stat_part.p, 0, sizeof(long long) * 4 * (size_t)slots * F, c->stream));
+                    fa.stat_part = c->stat_part.as<long long>();
+                    fa.stat_slots = slots;
+                    c->stat_slots = slots;
+                }
+            }
             if (lean) hipLaunchKernelGGL(k_finish_fast<true>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             else hipLaunchKernelGGL(k_finish_fast<false>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             int lgrid = 0;
@@ -1008,8 +1022,9 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
             double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
-            hipLaunchKernelGGL(k_stat_finalize, dim3((F + 255) / 256), dim3(256), 0, c->stream,
-                               c->stat.as<unsigned long long>(), F, n, dm, dv);
+            hipLaunchKernelGGL(k_stat_finalize, dim3(F), dim3(64), 0, c->stream,
+                               c->stat.as<unsigned long long>(), c->stat_slots ? c->stat_part.as<long long>() : nullptr,
+                               c->stat_slots, F, n, dm, dv);
         }
         if (host) {
             HIP_TRY(hipEventRecord(c->consumed_ev[b & 1], c->stream));
@@ -1089,7 +1104,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     if (c->in_ev) (void)hipEventDestroy(c->in_ev);
     if (c->sort_stream) { (void)hipStreamSynchronize(c->sort_stream); (void)hipStreamDestroy(c->sort_stream); }
     for (DevBuf* b : bufs) b->release();
-    c->cvt_in.release(); c->xchg.release();
+    c->cvt_in.release(); c->xchg.release(); c->stat_part.release();
     for (auto& b : c->cvt_out) b.release();
     for (int k = 0; k < 2; ++k) {
         c->host_stage[k].release();

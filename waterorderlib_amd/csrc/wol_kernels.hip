@@ -774,13 +774,26 @@ __device__ __forceinline__ void wol_stat_add_lane(const QOut& o, int f, double q
 }
 
 // mean and population variance of every frame from the accumulators (np.mean / np.var, ddof = 0)
-__global__ void k_stat_finalize(const unsigned long long* __restrict__ stat, int F, int n,
-                                double* __restrict__ mean, double* __restrict__ var) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per frame
+__global__ void __launch_bounds__(64)
+k_stat_finalize(const unsigned long long* __restrict__ stat, const long long* __restrict__ part, int slots,
+                int F, int n, double* __restrict__ mean, double* __restrict__ var) {
+    const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= F) return;
+    long long s[4] = {0, 0, 0, 0};
+    if (part) {   // the certification kernel's per-wave shares (integer sums: exact in any order)
+        const longlong4* p = reinterpret_cast<const longlong4*>(part) + (size_t)f * slots;
+        for (int k = lane; k < slots; k += 64) { const longlong4 v = p[k]; s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], off, 64);
+    }
+    if (lane != 0) return;
     const long long* a = reinterpret_cast<const long long*>(stat) + 4 * (size_t)f;
-    const double s1 = (double)a[0] * 9.313225746154785e-10 + (double)a[1] * 8.470329472543003e-22;   // 2^-30, 2^-70
-    const double s2 = (double)a[2] * 9.313225746154785e-10 + (double)a[3] * 8.470329472543003e-22;
+    s[0] += a[0]; s[1] += a[1]; s[2] += a[2]; s[3] += a[3];
+    const double s1 = (double)s[0] * 9.313225746154785e-10 + (double)s[1] * 8.470329472543003e-22;   // 2^-30, 2^-70
+    const double s2 = (double)s[2] * 9.313225746154785e-10 + (double)s[3] * 8.470329472543003e-22;
     const double m = s1 / (double)n;
     if (mean) mean[f] = m;
     if (var) var[f] = s2 / (double)n - m * m;

@@ -81,6 +81,8 @@ struct FastArgs {
     unsigned long long* stamps;  // diagnostic builds only
     int rows;               // 1: proposals come from k_search_rows (x reach counted in fine bins, its own eps)
     const unsigned* cnt4;   // per cell: populations of its four fine x bins as bytes (k_sort_in_row); k_search_rows only
+    long long* stat_part;   // [F][stat_slots][4]: per-wave partial sums of q, q^2 of k_finish_fast (zeroed by the host), or null
+    int stat_slots;
 };
 
 // sorted insert of `key` into k0 <= k1 <= ... <= k4 (the largest falls off): new k_i is the median of
@@ -557,18 +559,38 @@ k_finish_fast(FastArgs a) {
     __shared__ unsigned long long blk_stat[4];
     for (int f = (aff ? (int)(blockIdx.x & 7) : 0) + fstep * fsub; f < a.F && fsub < fgroups; f += fstep * fgroups) {
     long long sum_h = 0, sum_l = 0, sum_h2 = 0, sum_l2 = 0;  // this lane's share of frame f's sums of q, q^2
+    const FrameGrid& g = a.grids[f];
+    if (g.maxshell < 0) continue;  // all-pairs frame
+    const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+    const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
+#ifdef WOL_FINISH_PREFETCH
+    // key, proposal and own coordinates of the NEXT 256 waters are fetched while the current ones are certified
+    int kd3_n = 0; int4 pr_n; double4 mev_n;
+    {
+        const int s_ = min(kb * WOL_BLOCK + (int)threadIdx.x, a.n - 1);
+        const int64_t w_ = (int64_t)f * a.n + s_;
+        kd3_n = a.prop_key[w_]; pr_n = a.prop[w_]; mev_n = sp[s_];
+    }
+#endif
     for (int s0 = kb * WOL_BLOCK; s0 < a.n; s0 += KB * WOL_BLOCK) {  // uniform bounds: whole waves stay in the loop
         const int s = min(s0 + (int)threadIdx.x, a.n - 1);
         const bool live = s0 + (int)threadIdx.x < a.n;
         const int64_t w = (int64_t)f * a.n + s;
-        const FrameGrid& g = a.grids[f];
-        if (g.maxshell < 0) continue;  // all-pairs frame
-        const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
-        const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
+#ifdef WOL_FINISH_PREFETCH
+        const int kd3 = live ? kd3_n : 0;
+        const int4 pr_all = pr_n;
+        const double4 mev_all = mev_n;
+        {
+            const int s_ = min(s0 + KB * WOL_BLOCK + (int)threadIdx.x, a.n - 1);
+            const int64_t w_ = (int64_t)f * a.n + s_;
+            kd3_n = a.prop_key[w_]; pr_n = a.prop[w_]; mev_n = sp[s_];
+        }
+#else
         // key, proposal and own coordinates are fetched together (one round trip), the neighbours in a second one
         const int kd3 = live ? a.prop_key[w] : 0;
         const int4 pr_all = a.prop[w];
         const double4 mev_all = sp[s];
+#endif
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
         if constexpr (LEAN) { if (live && !slow) {
@@ -578,7 +600,12 @@ k_finish_fast(FastArgs a) {
             const int4 pr = pr_all;
             const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
+#ifdef WOL_EXP_FINISH_NOGATHER   // ablation build: timing only, results are wrong
+            const double4 nb[4] = {{mev.x + 2.5 + 1e-9 * pr.x, mev.y, mev.z, 0.0}, {mev.x, mev.y + 2.6 + 1e-9 * pr.y, mev.z, 0.0},
+                                   {mev.x, mev.y, mev.z + 2.7 + 1e-9 * pr.z, 0.0}, {mev.x - 2.8 - 1e-9 * pr.w, mev.y, mev.z, 0.0}};
+#else
             const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
+#endif
             // The minimum-image vectors d themselves stand in for the reference's (apos + d) - apos (wp:372-373) and
             // for tetraCosAng's second re-image: they differ by rounding of order ulp(apos), 1e-15 relative, which q
             // tolerates (|dq| < 1e-14) and the distance bins do not notice except on a bin edge -- there the
@@ -731,6 +758,29 @@ k_finish_fast(FastArgs a) {
     }
     if constexpr (LEAN) {
         if (a.out.stat) {
+            if (a.stat_part) {
+                // frame f is done for this wave: butterfly-sum the four integers over the wave and store them in the
+                // wave's own slot of the frame (k_stat_finalize adds the slots up).  No barrier, no atomic: with only
+                // a few passes of the block per frame, three block barriers per frame kept the waves in lockstep.
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    sum_h += __shfl_xor(sum_h, off, 64); sum_l += __shfl_xor(sum_l, off, 64);
+                    sum_h2 += __shfl_xor(sum_h2, off, 64); sum_l2 += __shfl_xor(sum_l2, off, 64);
+                }
+                if ((threadIdx.x & 63) == 0) {
+                    const int slot = kb * (WOL_BLOCK / 64) + (int)(threadIdx.x >> 6);
+                    if (slot < a.stat_slots) {
+                        longlong4 v;
+                        v.x = sum_h; v.y = sum_l; v.z = sum_h2; v.w = sum_l2;
+                        reinterpret_cast<longlong4*>(a.stat_part)[(size_t)f * a.stat_slots + slot] = v;
+                    } else {   // (cannot happen with the grids the host launches; kept exact all the same)
+                        unsigned long long* st = a.out.stat + 4 * (size_t)f;
+                        atomicAdd(&st[0], (unsigned long long)sum_h); atomicAdd(&st[1], (unsigned long long)sum_l);
+                        atomicAdd(&st[2], (unsigned long long)sum_h2); atomicAdd(&st[3], (unsigned long long)sum_l2);
+                    }
+                }
+                continue;
+            }
             // frame f is done for this block: butterfly-sum the four integers over each wave, combine
             // the waves in LDS, one thread adds the block's share to the frame's accumulators
             if (threadIdx.x < 4) blk_stat[threadIdx.x] = 0ull;
