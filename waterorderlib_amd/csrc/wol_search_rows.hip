@@ -296,12 +296,21 @@ k_search_rows(FastArgs a) {
         if (!overflow) {
             const unsigned char* __restrict__ ob8 = reinterpret_cast<const unsigned char*>(obins);
             int r = wave, i0 = 0;
-            int c0 = 0, c1 = 0, cnt = 0, d0 = 0, d1 = 0, d2 = 0;   // the current row's pieces (wave-uniform)
-#define WOL_ROW_PARAMS(rr)                                                                          \
-            do {                                                                                    \
-                c0 = rcnt[3 * (rr)]; c1 = rcnt[3 * (rr) + 1];                                       \
-                cnt = c0 + c1 + (int)rcnt[3 * (rr) + 2];                                            \
-                d0 = rsrc[3 * (rr)]; d1 = rsrc[3 * (rr) + 1] - c0; d2 = rsrc[3 * (rr) + 2] - c0 - c1; \
+            // the current row's pieces and everything else that is the same for all of its waters (wave-uniform: kept in
+            // scalar registers, recomputed when the wave moves to its next row)
+            int c0 = 0, c1 = 0, cnt = 0, d0 = 0, d1 = 0, d2 = 0, tb = 0, binbase = 0, obbase = -1;
+            float offy = 0.f, offz = 0.f;
+#define WOL_ROW_PARAMS(rr)                                                                                       \
+            do {                                                                                                 \
+                const int t_ = (rr) / 3, dzk_ = (rr) - 3 * t_;                                                   \
+                c0 = WOL_SGPR_I(rcnt[3 * (rr)]); c1 = WOL_SGPR_I(rcnt[3 * (rr) + 1]);                            \
+                cnt = c0 + c1 + WOL_SGPR_I(rcnt[3 * (rr) + 2]);                                                  \
+                d0 = WOL_SGPR_I(rsrc[3 * (rr)]); d1 = WOL_SGPR_I(rsrc[3 * (rr) + 1]) - c0;                       \
+                d2 = WOL_SGPR_I(rsrc[3 * (rr) + 2]) - c0 - c1;                                                   \
+                tb = WOL_SGPR_I(tbase[t_]);                                                                      \
+                binbase = 2 * t_ * nbw;                                 /* first 16-bit bin entry of the triple */ \
+                obbase = dzk_ == 0 ? -1 : (t_ * nbw + (dzk_ - 1)) * 4;  /* byte table of the rows below */       \
+                offy = WOL_SGPR_F(((float)t_ - yc) * fys); offz = WOL_SGPR_F((float)(dzk_ - 1) * fzs);           \
             } while (0)
             while (r < nrows) { WOL_ROW_PARAMS(r); if (cnt > 0) break; r += NW; }   // first non-empty row of this wave
             float4 vn;
@@ -312,8 +321,8 @@ k_search_rows(FastArgs a) {
                 // the current chunk of 64 waters
                 const float4 v = vn;
                 const int src = srcn, i = i0 + lane;
-                const int cc0 = c0, cc1 = c1, ccnt = cnt;
-                const int t = (int)(((float)r + 0.5f) * (1.0f / 3.0f)), dzk = r - 3 * t;
+                const int cc0 = c0, cc1 = c1, ccnt = cnt, ctb = tb, cbin = binbase, cob = obbase;
+                const float coffy = offy, coffz = offz;
                 // advance to the next chunk and start its fetch
                 i0 += 64;
                 if (i0 >= cnt) {
@@ -332,13 +341,12 @@ k_search_rows(FastArgs a) {
                     const int cx = (int)(tag & 0xFFu), sub = (int)((tag >> 8) & 3u), rank = (int)(tag >> 10);
                     const int sc = p0 ? 0 : p2 ? sxe + 1 : cx - x0 + 1;
                     const int bin = sc * WOL_XSUB + sub;
-                    const int below = dzk == 0 ? 0 : (int)ob8[(t * nbw + 2 * sc + (dzk - 1)) * 4 + sub];
-                    const int e = tbase[t] + (int)bins16[2 * t * nbw + bin] + below + rank;
+                    const int below = cob < 0 ? 0 : (int)ob8[cob + 8 * sc + sub];
+                    const int e = ctb + (int)bins16[cbin + bin] + below + rank;
                     const int o = (e >> 1) * 4 + (e & 1);
-                    const float offy = ((float)t - yc) * fys, offz = (float)(dzk - 1) * fzs;
                     recf[o] = __builtin_fmaf(v.x, WOL_ROWS_CSCALE, ((float)sc - xc) * fxs);
-                    recf[o + 2] = __builtin_fmaf(v.y, WOL_ROWS_CSCALE, offy);
-                    recg[o] = __builtin_fmaf(v.z, WOL_ROWS_CSCALE, offz);
+                    recf[o + 2] = __builtin_fmaf(v.y, WOL_ROWS_CSCALE, coffy);
+                    recg[o] = __builtin_fmaf(v.z, WOL_ROWS_CSCALE, coffz);
                     recg[o + 2] = __uint_as_float(((unsigned)e << WOL_SLOT_BITS) | (unsigned)src);
                 }
             }
