@@ -671,6 +671,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             WOL_TRY(c->prop.ensure(sizeof(int4) * (size_t)F * n));
             WOL_TRY(c->prop_key.ensure(sizeof(int) * (size_t)F * n));
             HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+            // every water starts as "not certifiable": one the proposal kernel does not reach (the 3-D tile kernel
+            // enumerates at most 255 waters per cell) is then finished by the exact kernel instead of being certified
+            // from whatever the buffer held
+            HIP_TRY(hipMemsetAsync(c->prop_key.p, 0xFF, sizeof(int) * (size_t)F * n, c->stream));
             WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
             hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->stream, a.grids, a.cell_start, S.level.as<int>());
             FastArgs fa;
