@@ -17,6 +17,12 @@ pytestmark = pytest.mark.gpu
 Q_TOL = 1e-12
 
 
+@pytest.fixture(scope="module")
+def wp_mod():
+    from waterorderlib_amd import water_properties
+    return water_properties
+
+
 def _np_hist(q, bins=500):
     return np.histogram(q, bins=bins, range=[0.0, 1.0], density=False)[0].astype(np.int64)
 
@@ -411,3 +417,33 @@ def test_two_ranks_over_rccl_when_two_gpus_are_present():
     for rank, qh1, m1, qh2, dh2, m2, v2 in got:
         assert np.array_equal(qh1, one.qhist) and np.array_equal(m1, one.mean)
         assert np.array_equal(qh2, one.qhist) and np.array_equal(dh2, one.dhist) and np.array_equal(m2, one.mean) and np.array_equal(v2, one.var)
+
+
+@pytest.mark.parametrize("rows", [1, 0])
+def test_cells_with_hundreds_of_waters(wp_mod, oracle, rows):
+    """Blobs far denser than any liquid: cells with more than 255 waters (the 3-D tile kernel enumerates at most 255 per
+    cell; waters it does not reach must be finished by the exact kernel, never read from an uninitialised proposal
+    buffer -- soak seed 205 faulted the GPU there), fresh contexts, a second call on the same context after a
+    different frame"""
+    from waterorderlib_amd import _lib
+    rng = np.random.default_rng(205)
+    box = np.array([110.2, 37.9, 101.2])
+    n = 20000
+    pos = rng.random((n, 3)) * box
+    centres = rng.random((5, 3)) * box
+    k = n // 3
+    pos[:k] = centres[rng.integers(5, size=k)] + rng.normal(0.0, 2.5, size=(k, 3))
+    pos += rng.integers(-1, 2, size=pos.shape) * box
+    q_o, idx_o, dist_o, ang_o = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    for attempt in range(2):
+        c = _lib.Context(0)
+        c.set_option("path", 3)
+        c.set_option("search_rows", rows)
+        if attempt == 1:   # leave other proposals in the buffers first
+            other = rng.random((n, 3)) * box
+            wp_mod.getOrderParamq(other, other, box, ctx=c)
+        q, idx, dist, ang = wp_mod.getOrderParamq(pos, pos, box, full=True, ctx=c)
+        assert np.array_equal(idx, idx_o) and np.array_equal(dist, dist_o, equal_nan=True)
+        np.testing.assert_allclose(q, q_o, rtol=0, atol=Q_TOL)
+        np.testing.assert_allclose(ang, ang_o, rtol=0, atol=1e-9, equal_nan=True)
+        c.close()
