@@ -149,6 +149,12 @@ def main():
     ap.add_argument("--e2e-frames", type=int, default=192, help="host frames of the end-to-end leg")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON: everything libraries print there (RCCL announces its version on
+    # stdout when a communicator comes up) goes to stderr instead, at the file-descriptor level
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from waterorderlib_amd import _lib, engine, synth
@@ -318,7 +324,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # reported on rank 0 of the one-GPU run only
             pos_host = batches[args.warmup][0].to(torch.float64).cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(pos_host, box, min(args.cpu_sample_waters, n), len(os.sched_getaffinity(0)))
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
