@@ -563,34 +563,15 @@ k_finish_fast(FastArgs a) {
     if (g.maxshell < 0) continue;  // all-pairs frame
     const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
     const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
-#ifdef WOL_FINISH_PREFETCH
-    // key, proposal and own coordinates of the NEXT 256 waters are fetched while the current ones are certified
-    int kd3_n = 0; int4 pr_n; double4 mev_n;
-    {
-        const int s_ = min(kb * WOL_BLOCK + (int)threadIdx.x, a.n - 1);
-        const int64_t w_ = (int64_t)f * a.n + s_;
-        kd3_n = a.prop_key[w_]; pr_n = a.prop[w_]; mev_n = sp[s_];
-    }
-#endif
     for (int s0 = kb * WOL_BLOCK; s0 < a.n; s0 += KB * WOL_BLOCK) {  // uniform bounds: whole waves stay in the loop
         const int s = min(s0 + (int)threadIdx.x, a.n - 1);
         const bool live = s0 + (int)threadIdx.x < a.n;
         const int64_t w = (int64_t)f * a.n + s;
-#ifdef WOL_FINISH_PREFETCH
-        const int kd3 = live ? kd3_n : 0;
-        const int4 pr_all = pr_n;
-        const double4 mev_all = mev_n;
-        {
-            const int s_ = min(s0 + KB * WOL_BLOCK + (int)threadIdx.x, a.n - 1);
-            const int64_t w_ = (int64_t)f * a.n + s_;
-            kd3_n = a.prop_key[w_]; pr_n = a.prop[w_]; mev_n = sp[s_];
-        }
-#else
         // key, proposal and own coordinates are fetched together (one round trip), the neighbours in a second one
+        // (fetching the next 256 waters' share ahead of time was measured: no change, the gathers are what costs)
         const int kd3 = live ? a.prop_key[w] : 0;
         const int4 pr_all = a.prop[w];
         const double4 mev_all = sp[s];
-#endif
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
         if constexpr (LEAN) { if (live && !slow) {
@@ -600,9 +581,9 @@ k_finish_fast(FastArgs a) {
             const int4 pr = pr_all;
             const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
-#ifdef WOL_EXP_FINISH_NOGATHER   // ablation build: timing only, results are wrong
-            const double4 nb[4] = {{mev.x + 2.5 + 1e-9 * pr.x, mev.y, mev.z, 0.0}, {mev.x, mev.y + 2.6 + 1e-9 * pr.y, mev.z, 0.0},
-                                   {mev.x, mev.y, mev.z + 2.7 + 1e-9 * pr.z, 0.0}, {mev.x - 2.8 - 1e-9 * pr.w, mev.y, mev.z, 0.0}};
+#ifdef WOL_EXP_FINISH_COALESCED   // ablation build: timing only, results are wrong (neighbours = the next four slots)
+            const double4 nb[4] = {sp[min(s + 1 + (pr.x & 0), a.n - 1)], sp[min(s + 2 + (pr.y & 0), a.n - 1)],
+                                   sp[min(s + 3 + (pr.z & 0), a.n - 1)], sp[min(s + 4 + (pr.w & 0), a.n - 1)]};
 #else
             const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
 #endif
@@ -651,7 +632,11 @@ k_finish_fast(FastArgs a) {
             const double rg = (dmax > cwmin - 1e-4) ? wol_guaranteed_radius(c, g, a.rows) : cwmin;
             const double d3s = (dmax * dmax) * g.S;
             // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity
+#ifdef WOL_EXP_FINISH_COALESCED
+            if (!(dmax > -1.0) || d3s == 12345.678) {
+#else
             if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)eps_u || !(emax < 0.49)) {
+#endif
                 slow = true;
             } else {
                 // the six terms are summed in ascending order of their values: the result must not depend
