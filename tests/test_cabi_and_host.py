@@ -96,3 +96,46 @@ def test_traj_object_mirror():
     fr = next(iter(obj.traj))
     assert fr.xyz.shape == (40, 3) and list(fr.box.values[:3]) == [10.0, 11.0, 12.0]
     assert len(TrajObject(xyz, boxes, lenWat=4, stride=2).traj) == 2
+
+
+def test_c_abi_shard_bounds_equal_the_python_ones():
+    """wol_shard_bounds (what a C / MPI caller uses) is a pure function: callable without a GPU"""
+    from waterorderlib_amd import _lib, engine
+    for T in (0, 1, 7, 25, 1000, 8001):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert _lib.shard_bounds(T, r, world) == engine.shard_bounds(T, r, world)
+    with pytest.raises(_lib.WolError):
+        _lib.shard_bounds(10, 3, 3)
+
+
+def test_streaming_driver_takes_frames_lazily_in_chunks():
+    """orderParam_lib._frame_chunks: the trajectory iterator is consumed once, frame by frame, and at most one chunk of
+    frames is held (the reference iterates pytraj.iterload, orderParam_lib.py:1458)"""
+    from waterorderlib_amd import orderParam_lib as opl
+    from waterorderlib_amd.TrajObject import Frame
+    made = []
+
+    def frames():
+        for t in range(23):
+            made.append(t)
+            yield Frame(np.full((12, 3), float(t)), [10.0 + t, 11.0, 12.0])
+
+    seen = []
+    for t0, xyz, boxes in opl._frame_chunks(frames(), slice(0, 8), chunk_bytes=5 * 8 * 3 * 8):
+        assert len(made) <= t0 + len(xyz)          # nothing beyond the current chunk has been generated yet
+        assert xyz.shape[1:] == (8, 3) and len(xyz) <= 5 and boxes.shape == (len(xyz), 3)
+        assert np.all(xyz[:, 0, 0] == np.arange(t0, t0 + len(xyz))) and boxes[0, 0] == 10.0 + t0
+        seen.extend(range(t0, t0 + len(xyz)))
+    assert seen == list(range(23))
+    # an index array selects atoms like pos[watInds] (orderParam_lib.py:1462)
+    sel = np.array([0, 4, 8])
+    chunks = list(opl._frame_chunks(frames(), sel, chunk_bytes=1 << 20))
+    assert len(chunks) == 1 and chunks[0][1].shape == (23, 3, 3)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr and out.stdout == ""
