@@ -301,7 +301,9 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
 // ---------------------------------------------------------------------------------------------
 #define WOL_L1_MAXROWS 4080   // nz * ny rows counted in LDS by level 1 (three tables + the chunk staging within 160 KB)
 #define WOL_L2_MAXNX 128      // cells of a row handled by one wave of level 2
+#ifndef WOL_L1_CHUNK
 #define WOL_L1_CHUNK 3            // waters per thread and chunk of level 1 (chunk = 3 * 1024 waters: 96 KB of staging)
+#endif
 #define WOL_L1_CHUNK_BIG 2        // ... for frames with more rows than WOL_L1_MAXROWS (tables up to WOL_L1_MAXROWS_BIG rows)
 #define WOL_L1_MAXROWS_BIG 6800
 // dynamic LDS of the level-1 kernels for a frame with nrow cell rows and chunks of ch * 1024 waters

@@ -27,7 +27,9 @@
 // per layer -- two tiles of 357 for 512 lanes, one of 714 for 768 (fewer halo rows, half the per-tile work).  (A
 // 384-thread form for still smaller boxes was measured slower: idle waves of a half-empty tile cost little.)
 #define WOL_ROWS_BLOCK_A 512
+#ifndef WOL_ROWS_CAPP_A
 #define WOL_ROWS_CAPP_A 1280
+#endif
 #define WOL_ROWS_BLOCK_B 768
 #define WOL_ROWS_CAPP_B 1920
 #define WOL_ROWS_PADP 8        // head-room pairs behind the last triple (incl. the dummy pair)
@@ -40,7 +42,10 @@
 #define WOL_ROWS_MAXSX (252 / WOL_XSUB - 2)   // (sx + 2) * XSUB bins <= 252 (four bins per lane in the scan)
 #define WOL_ROWS_BINW 704      // 32-bit words of bin counters: sum over the triples of ceil((bins + 1) / 2)
 #define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
-#define WOL_ROWS_TARGET(block) (((block) * 97) / 100)
+#ifndef WOL_ROWS_ROUNDS
+#define WOL_ROWS_ROUNDS 1      // sweep rounds per wave a tile is sized for (experiments: 2 = tiles twice as tall)
+#endif
+#define WOL_ROWS_TARGET(block) (((block) * 97 * WOL_ROWS_ROUNDS) / 100)
 #define WOL_ROWS_CSCALE 0.0009765625f   // 2^-10
 #ifndef WOL_ROWS_WPS
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
