@@ -403,11 +403,13 @@ k_search_rows(FastArgs a) {
                     const int pb = lo >> 1, pe = live ? (hi + 1) >> 1 : pb;
                     win[dt] = ((unsigned)(pe - pb) << 16) | (unsigned)pb;
                 }
+#ifndef WOL_EXP_NO_WINSORT
                 {
                     const unsigned a01 = max(win[0], win[1]), b01 = min(win[0], win[1]);
                     const unsigned c2 = max(b01, win[2]);
                     win[2] = min(b01, win[2]); win[0] = max(a01, c2); win[1] = min(a01, c2);
                 }
+#endif
 #pragma unroll
                 for (int dt = 0; dt < 3; ++dt) {
 #ifdef WOL_EXP_NO_SWEEP   // ablation build: timing only, results are wrong
