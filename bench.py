@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run "
                          "(default: the committed counter pass, %s, when the workload matches it)" % COUNTERS_FILE)
+    ap.add_argument("--dyn-tiles", type=int, default=-2, help="proposal kernel tile order: 1 per-XCD counters, 0 static (default: library default)")
+    ap.add_argument("--stages", type=int, default=-1, help="pipe depth of the overlapped trajectory path (2 / 3)")
     ap.add_argument("--want-q", action="store_true", help="also write per-water q (8 B per water more per step)")
     ap.add_argument("--rows-block", type=int, default=-1, help="force the proposal kernel's instantiation (512 / 768)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory (PCIe-inclusive) leg")
@@ -200,6 +202,10 @@ def main():
         ctx.set_option("sort_parts", args.sort_parts)
     if args.search_margin >= 0:
         ctx.set_option("search_margin", args.search_margin)
+    if args.stages >= 0:
+        ctx.set_option("stages", args.stages)
+    if args.dyn_tiles >= -1:
+        ctx.set_option("dyn_tiles", args.dyn_tiles)
     if args.rows_block >= 0:
         ctx.set_option("rows_block", args.rows_block)
 

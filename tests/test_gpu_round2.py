@@ -447,3 +447,66 @@ def test_cells_with_hundreds_of_waters(wp_mod, oracle, rows):
         np.testing.assert_allclose(q, q_o, rtol=0, atol=Q_TOL)
         np.testing.assert_allclose(ang, ang_o, rtol=0, atol=1e-9, equal_nan=True)
         c.close()
+
+
+def test_tile_order_of_the_proposal_kernel_does_not_show_in_the_results(oracle):
+    """the blocks of k_search_rows draw their tiles from per-XCD counters (default) or walk them in a fixed order
+    (dyn_tiles = 0): same proposals either way -- every output identical, and equal to the oracle's.  Frames with
+    different boxes (different tile counts per frame) and fewer than eight frames (no XCD grouping) included."""
+    from waterorderlib_amd import _lib, engine, synth
+    n = 6000
+    xyz, boxes = synth.water_frames(n, 1, seed=17)
+    rng = np.random.default_rng(17)
+    for T in (70, 5):
+        scale = 1.0 + 0.12 * rng.random((T, 3))
+        frames = xyz[0][None] * scale[:, None, :] + rng.normal(0.0, 0.02, size=(T, n, 3))
+        bx = boxes[0][None] * scale
+        out = {}
+        for dyn in (1, 0):
+            ctx = _lib.Context(0)
+            ctx.set_option("path", 3)
+            ctx.set_option("dyn_tiles", dyn)
+            out[dyn] = engine.tet_order_traj(frames, bx, want_q=True, ctx=ctx)
+            assert ctx.counter("rows_block") in (512, 768)
+            ctx.close()
+        a, b = out[1], out[0]
+        assert np.array_equal(a.q, b.q) and np.array_equal(a.qhist, b.qhist) and np.array_equal(a.dhist, b.dhist)
+        assert np.array_equal(a.mean, b.mean) and np.array_equal(a.var, b.var)
+        mean, var, qh, dh = oracle.tet_order_traj(frames, bx)
+        assert np.array_equal(a.qhist, qh) and np.array_equal(a.dhist, dh)
+        np.testing.assert_allclose(a.mean, mean, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("stages", [2, 3])
+def test_overlapped_batches_equal_the_serial_run(stages):
+    """option "overlap": the sort of one batch runs on a second stream beside the proposal kernel of the batch before
+    (stages = 3: the certification of the batch before that on a third).  Several batches per call (each batch owns one of
+    three sets of intermediate arrays, so the fourth batch reuses the first's), a ragged last batch below the overlap
+    threshold, and back-to-back calls that run into each other: everything identical to the serial run."""
+    import torch
+    from waterorderlib_amd import _lib, engine, synth
+    xyz, boxes = synth.water_frames(4000, 300, seed=23)
+    dev = torch.from_numpy(xyz).cuda()
+    ref_ctx = _lib.Context(0)
+    ref = engine.tet_order_traj(dev, boxes, want_q=True, ctx=ref_ctx)
+    torch.cuda.synchronize()
+    ctx = _lib.Context(0)
+    ctx.set_option("overlap", 1)
+    ctx.set_option("stages", stages)
+    for resident in (0, 1):
+        ctx.set_option("inputs_resident", resident)
+        for fpb in (64, 72, 0):                  # 5 batches (64 x 4 + 44: the last below the threshold), 72 x 4 + 12, one batch
+            ctx.set_option("frames_per_batch", fpb)
+            res = engine.tet_order_traj(dev, boxes, want_q=True, ctx=ctx)
+            assert torch.equal(res.q, ref.q) and torch.equal(res.qhist, ref.qhist) and torch.equal(res.dhist, ref.dhist)
+            assert torch.equal(res.mean, ref.mean) and torch.equal(res.var, ref.var)
+    # calls enqueued back to back without a synchronisation in between: the sort of the second starts under the first
+    ctx.set_option("frames_per_batch", 64)
+    parts = [engine.tet_order_traj(dev[k:k + 100], boxes[k:k + 100], want_q=True, ctx=ctx) for k in (0, 100, 200)]
+    assert torch.equal(torch.cat([p.q for p in parts]), ref.q)
+    assert torch.equal(sum(p.qhist for p in parts), ref.qhist)
+    # ... and a per-frame call right behind them (it takes over the first set of arrays)
+    from waterorderlib_amd import water_properties as wp
+    q0 = wp.getOrderParamq(xyz[0], xyz[0], boxes[0], ctx=ctx)
+    np.testing.assert_allclose(q0, ref.q[0].cpu().numpy(), rtol=0, atol=Q_TOL)
+    ctx.close(); ref_ctx.close()

@@ -78,6 +78,7 @@ struct PinBuf {
 
 }  // namespace
 
+#define WOL_NSETS 3   // batches in flight in the trajectory path (sort / proposal / certification)
 struct wol_ctx {
     int device = 0;
     int num_cus = 256;
@@ -91,18 +92,21 @@ struct wol_ctx {
     bool time_kernels = false;
     bool lds_sort = true;
     // workspace
-    // cell-sorted data is double-buffered: the sort of the next batch runs on `sort_stream` beside the
-    // search / finish kernels of the current batch on `stream` (the sort is memory-bound, the search
-    // VALU-bound); events hand the sets back and forth
+    // Three batches are in flight in the trajectory path: the sort of batch k+2 (memory-bound) on `sort_stream`, the
+    // proposal kernel of batch k+1 (bound by the vector issue rate) on `search_stream` and the certification of batch k
+    // (gathers + fp64) on `stream`, the stream the caller sees.  Each batch owns one set of intermediate arrays; events
+    // hand the sets from stage to stage.
     struct SortSet {
-        DevBuf sorted, sorted32, cells, grids, level, cnt4;
-        hipEvent_t sorted_ev = nullptr;  // recorded on the sort stream when the set is filled
-        hipEvent_t free_ev = nullptr;    // recorded on `stream` when its last reader is done
+        DevBuf sorted, sorted32, cells, grids, level, cnt4, prop, prop_key, work;
+        hipEvent_t sorted_ev = nullptr;    // recorded on the sort stream when the set is filled
+        hipEvent_t searched_ev = nullptr;  // recorded on the search stream when the proposals are written
+        hipEvent_t free_ev = nullptr;      // recorded on `stream` when its last reader is done
         bool used = false;
-    } sets[2];
+    } sets[WOL_NSETS];
     int next_set = 0;
-    hipStream_t sort_stream = nullptr;
+    hipStream_t sort_stream = nullptr, search_stream = nullptr;
     hipEvent_t in_ev = nullptr;
+    hipEvent_t scratch_ev = nullptr;   // recorded behind every sort: the sorts share scratch arrays whichever stream they run on
     bool search_rows = true;  // proposal kernel: row-merged tiles (wol_search_rows.hip); false = 3-D tiles (wol_search_fast.hip)
     bool overlap = false;  // measured on MI355X: the sort and the search contend for the same CU slots and
                            // memory latency, running them side by side gains nothing; kept as an opt-in
@@ -111,9 +115,11 @@ struct wol_ctx {
     int last_rows_block = 0;
     int force_rows_block = 0;  // 0 = per batch by lane fill; 512 / 768 = that k_search_rows instantiation (tests, tuning)
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
+    int dyn_tiles = 1;       // 1: the proposal kernel's blocks draw their tiles from per-XCD counters (default); 0: static tile order
+    int stages = 2;          // pipe depth of the trajectory path: 2 = sort | proposal + certification, 3 = sort | proposal | certification
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
-    DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, prop, prop_key, stamps, scan_tot;
+    DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, stamps, scan_tot;
     PinBuf grids_host;
     DevBuf cvt_in, cvt_out[4], xchg, stat_part;
     int stat_slots = 0;   // slots per frame of stat_part in the last batch (0: unused)   // float <-> double conversion staging of the typed per-frame calls; exchange buffer of the sharded call
@@ -391,7 +397,7 @@ int resident_grid(wol_ctx* c, K kernel, int block, size_t dyn_lds, int64_t work_
     return WOL_OK;
 }
 
-int begin_timing(wol_ctx* c, std::pair<hipEvent_t, hipEvent_t>* ev) {
+int begin_timing(wol_ctx* c, std::pair<hipEvent_t, hipEvent_t>* ev, hipStream_t st = nullptr) {
     if (c->ev_free.empty()) {
         hipEvent_t a, b;
         HIP_TRY(hipEventCreate(&a));
@@ -401,12 +407,12 @@ int begin_timing(wol_ctx* c, std::pair<hipEvent_t, hipEvent_t>* ev) {
         *ev = c->ev_free.back();
         c->ev_free.pop_back();
     }
-    HIP_TRY(hipEventRecord(ev->first, c->stream));
+    HIP_TRY(hipEventRecord(ev->first, st ? st : c->stream));
     return WOL_OK;
 }
 
-int end_timing(wol_ctx* c, const std::pair<hipEvent_t, hipEvent_t>& ev) {
-    HIP_TRY(hipEventRecord(ev.second, c->stream));
+int end_timing(wol_ctx* c, const std::pair<hipEvent_t, hipEvent_t>& ev, hipStream_t st = nullptr) {
+    HIP_TRY(hipEventRecord(ev.second, st ? st : c->stream));
     c->ev_used.push_back(ev);
     return WOL_OK;
 }
@@ -438,7 +444,7 @@ struct HistArgs {
 // out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
 template <typename T>
 int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
-                int64_t sub_stride, int ns, double low, double high, QOut out, bool allow_pipe = false) {
+                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0) {
     const int n = fv.n;
     c->stat_slots = 0;   // (set again below when the certification kernel keeps per-wave partial sums)
     if (F <= 0 || ns <= 0) return WOL_OK;
@@ -475,26 +481,32 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
 
     if (n_cell_frames > 0) {
         wol_ctx::SortSet& S = c->sets[c->next_set];
-        c->next_set ^= 1;
+        c->next_set = (c->next_set + 1) % WOL_NSETS;
         // the sort goes to the second stream when this is a large device-resident batch (the trajectory
         // path): it then overlaps the previous batch's search / finish kernels on the main stream
-        const bool pipe = c->overlap && allow_pipe && F >= 64;
+        const bool pipe = c->overlap && allow_pipe != 0 && F >= 64;
         if (!S.sorted_ev) {
             HIP_TRY(hipEventCreateWithFlags(&S.sorted_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.searched_ev, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&S.free_ev, hipEventDisableTiming));
         }
-        hipStream_t ss = c->stream;
+        hipStream_t ss = c->stream, qs = c->stream;   // the streams of the sort and of the proposal kernel
         if (pipe) {
             if (!c->sort_stream) HIP_TRY(hipStreamCreateWithFlags(&c->sort_stream, hipStreamNonBlocking));
+            if (!c->search_stream) HIP_TRY(hipStreamCreateWithFlags(&c->search_stream, hipStreamNonBlocking));
             if (!c->in_ev) HIP_TRY(hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
             ss = c->sort_stream;
+            if (c->stages >= 3) qs = c->search_stream;
             if (!c->inputs_resident) {
-                // the frames may be the product of work the caller enqueued earlier on its stream
-                HIP_TRY(hipEventRecord(c->in_ev, c->stream));
+                // the frames may be the product of work the caller enqueued earlier on its stream: the first batch of a
+                // call marks that point, the later batches of the call wait for the same mark (not for each other)
+                if (allow_pipe == 1) HIP_TRY(hipEventRecord(c->in_ev, c->stream));
                 HIP_TRY(hipStreamWaitEvent(ss, c->in_ev, 0));
             }
             if (S.used) HIP_TRY(hipStreamWaitEvent(ss, S.free_ev, 0));  // last readers of this set are done
         }
+        if (c->scratch_ev) HIP_TRY(hipStreamWaitEvent(ss, c->scratch_ev, 0));
+        else HIP_TRY(hipEventCreateWithFlags(&c->scratch_ev, hipEventDisableTiming));
         WOL_TRY(S.grids.ensure(sizeof(FrameGrid) * (size_t)F));
         WOL_TRY(S.cells.ensure(sizeof(int) * (size_t)cell_total));
         WOL_TRY(S.sorted.ensure(sizeof(double4) * (size_t)F * n));
@@ -592,16 +604,25 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             if (!c->sort_rows_lds_set) {
                 const int lds_a = (int)wol_sort_rows_lds(WOL_L1_MAXROWS, WOL_L1_CHUNK);
                 const int lds_b = (int)wol_sort_rows_lds(WOL_L1_MAXROWS_BIG, WOL_L1_CHUNK_BIG);
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                const int lds_p = (int)wol_sort_rows_lds(WOL_L1_MAXROWS, WOL_L1_CHUNK_PIPE, WOL_L1_BLOCK_PIPE);
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double, WOL_SORT_BLOCK, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double, WOL_L1_BLOCK_PIPE, WOL_L1_CHUNK_PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float, WOL_L1_BLOCK_PIPE, WOL_L1_CHUNK_PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 c->sort_rows_lds_set = 1;
             }
-            if (P == 1) {
-                hipLaunchKernelGGL(k_sort_rows<T>, dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
+            if (P == 1 && pipe) {
+                // beside the proposal kernel of the previous batch: eight waves and a third of the LDS per block, so that
+                // the two share a CU instead of taking turns
+                hipLaunchKernelGGL((k_sort_rows<T, WOL_L1_BLOCK_PIPE, WOL_L1_CHUNK_PIPE>), dim3(F), dim3(WOL_L1_BLOCK_PIPE),
+                                   wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_PIPE, WOL_L1_BLOCK_PIPE), ss, fv,
+                                   S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
+            } else if (P == 1) {
+                hipLaunchKernelGGL((k_sort_rows<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
             } else {
                 WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * P * ro_stride));   // per-block row counts, then cursors
@@ -641,9 +662,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             WOL_TRY(finish_cell_sort());
         }
 
+        HIP_TRY(hipEventRecord(c->scratch_ev, ss));
         if (pipe) {
             HIP_TRY(hipEventRecord(S.sorted_ev, ss));
-            HIP_TRY(hipStreamWaitEvent(c->stream, S.sorted_ev, 0));
+            HIP_TRY(hipStreamWaitEvent(use_fast ? qs : c->stream, S.sorted_ev, 0));
         }
         c->last_set = &S;
 
@@ -668,15 +690,14 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         if (use_fast) {
             WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)F * n));
             WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
-            WOL_TRY(c->prop.ensure(sizeof(int4) * (size_t)F * n));
-            WOL_TRY(c->prop_key.ensure(sizeof(int) * (size_t)F * n));
-            HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+            WOL_TRY(S.prop.ensure(sizeof(int4) * (size_t)F * n));
+            WOL_TRY(S.prop_key.ensure(sizeof(int) * (size_t)F * n));
             // every water starts as "not certifiable": one the proposal kernel does not reach (the 3-D tile kernel
             // enumerates at most 255 waters per cell) is then finished by the exact kernel instead of being certified
             // from whatever the buffer held
-            HIP_TRY(hipMemsetAsync(c->prop_key.p, 0xFF, sizeof(int) * (size_t)F * n, c->stream));
+            HIP_TRY(hipMemsetAsync(S.prop_key.p, 0xFF, sizeof(int) * (size_t)F * n, qs));
             WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
-            hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->stream, a.grids, a.cell_start, S.level.as<int>());
+            hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, S.level.as<int>());
             FastArgs fa;
             fa.level = S.level.as<int>();
             fa.grids = a.grids; fa.sorted = a.sorted; fa.sorted32 = s32; fa.cell_start = a.cell_start;
@@ -686,11 +707,17 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             fa.slow_list = c->slow_list.as<unsigned long long>();
             fa.slow_count = c->slow_count.as<int>();
             fa.fast_q = (out.ang == nullptr) ? 1 : 0;
-            fa.prop = c->prop.as<int4>();
-            fa.prop_key = c->prop_key.as<int>();
+            fa.prop = S.prop.as<int4>();
+            fa.prop_key = S.prop_key.as<int>();
             fa.stamps = nullptr;
             fa.rows = rows_kernel ? 1 : 0;
             fa.cnt4 = cnt4;
+            fa.work = nullptr;
+            if (rows_kernel && c->dyn_tiles != 0) {
+                WOL_TRY(S.work.ensure(sizeof(int) * 16 * 8));
+                HIP_TRY(hipMemsetAsync(S.work.p, 0, sizeof(int) * 16 * 8, qs));
+                fa.work = S.work.as<int>();
+            }
 #ifdef WOL_PHASE_STAMPS
             WOL_TRY(c->stamps.ensure(sizeof(unsigned long long) * 8));
             fa.stamps = c->stamps.as<unsigned long long>();
@@ -702,11 +729,16 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             else if (rows_block == WOL_ROWS_BLOCK_B) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>, WOL_ROWS_BLOCK_B, 0, ftotal, &fgrid, c->search_margin));
             else WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>, WOL_ROWS_BLOCK_A, 0, ftotal, &fgrid, c->search_margin));
             if (fa.xcd_affine) fgrid = std::max(8, (fgrid / 8) * 8);
-            if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-            if (!rows_kernel) hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, c->stream, fa);
-            else if (rows_block == WOL_ROWS_BLOCK_B) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_B), 0, c->stream, fa);
-            else hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_A), 0, c->stream, fa);
-            if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+            if (c->time_kernels) WOL_TRY(begin_timing(c, &ev, qs));
+            if (!rows_kernel) hipLaunchKernelGGL(k_search_fast, dim3(fgrid), dim3(WOL_FAST_BLOCK), 0, qs, fa);
+            else if (rows_block == WOL_ROWS_BLOCK_B) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_B), 0, qs, fa);
+            else hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_A), 0, qs, fa);
+            if (c->time_kernels) WOL_TRY(end_timing(c, ev, qs));
+            if (pipe && qs != c->stream) {   // the certification stage follows on the caller-visible stream
+                HIP_TRY(hipEventRecord(S.searched_ev, qs));
+                HIP_TRY(hipStreamWaitEvent(c->stream, S.searched_ev, 0));
+            }
+            HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
             const int64_t wtotal = (int64_t)F * n;
             int ggrid = 0;
             const bool lean = fa.fast_q && !out.nn_idx && !out.nn_dist;
@@ -847,6 +879,7 @@ int shell_setup(wol_ctx* c, RealSrc pos, int n, RealSrc sub, int ns, const doubl
     }
     wol_ctx::SortSet& S = c->sets[0];
     if (c->sort_stream) HIP_TRY(hipStreamSynchronize(c->sort_stream));  // rare path: keep it simple
+    if (c->search_stream) HIP_TRY(hipStreamSynchronize(c->search_stream));
     WOL_TRY(c->grids_host.ensure(sizeof(FrameGrid)));
     FrameGrid* gh = c->grids_host.as<FrameGrid>();
     // cells as wide as the reach (27-cell walk) for short reaches, half the reach (125 cells) for long ones: the
@@ -1022,7 +1055,7 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
             HIP_TRY(hipMemsetAsync(c->stat.p, 0, sizeof(unsigned long long) * 4 * (size_t)F, c->stream));
             out.stat = c->stat.as<unsigned long long>();
         }
-        WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, !host));
+        WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, host ? 0 : (b == 0 ? 1 : 2)));
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
             double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
@@ -1099,14 +1132,17 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->cellid, &c->rank, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->prop, &c->prop_key, &c->stamps, &c->scan_tot};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->stamps, &c->scan_tot};
     for (auto& S : c->sets) {
-        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release();
+        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release(); S.prop.release(); S.prop_key.release(); S.work.release();
+        if (S.searched_ev) (void)hipEventDestroy(S.searched_ev);
         if (S.sorted_ev) (void)hipEventDestroy(S.sorted_ev);
         if (S.free_ev) (void)hipEventDestroy(S.free_ev);
     }
     if (c->in_ev) (void)hipEventDestroy(c->in_ev);
+    if (c->scratch_ev) (void)hipEventDestroy(c->scratch_ev);
     if (c->sort_stream) { (void)hipStreamSynchronize(c->sort_stream); (void)hipStreamDestroy(c->sort_stream); }
+    if (c->search_stream) { (void)hipStreamSynchronize(c->search_stream); (void)hipStreamDestroy(c->search_stream); }
     for (DevBuf* b : bufs) b->release();
     c->cvt_in.release(); c->xchg.release(); c->stat_part.release();
     for (auto& b : c->cvt_out) b.release();
@@ -1161,6 +1197,10 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->force_rows_block = v;
     } else if (k == "sort_parts") {
         c->sort_parts = (int)value;
+    } else if (k == "dyn_tiles") {
+        c->dyn_tiles = (int)value;
+    } else if (k == "stages") {
+        c->stages = (int)value;
     } else if (k == "search_margin") {
         c->search_margin = (int)value;
     } else if (k == "overlap") {

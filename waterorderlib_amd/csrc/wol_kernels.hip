@@ -304,11 +304,13 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
 #ifndef WOL_L1_CHUNK
 #define WOL_L1_CHUNK 3            // waters per thread and chunk of level 1 (chunk = 3 * 1024 waters: 96 KB of staging)
 #endif
+#define WOL_L1_BLOCK_PIPE 512     // level-1 block when the sort runs beside the proposal kernel of another batch ...
+#define WOL_L1_CHUNK_PIPE 2       // ... and its waters per thread and chunk: 8 waves, 37 KB of staging
 #define WOL_L1_CHUNK_BIG 2        // ... for frames with more rows than WOL_L1_MAXROWS (tables up to WOL_L1_MAXROWS_BIG rows)
 #define WOL_L1_MAXROWS_BIG 6800
 // dynamic LDS of the level-1 kernels for a frame with nrow cell rows and chunks of ch * 1024 waters
-__host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch) {
-    return (size_t)ch * WOL_SORT_BLOCK * (sizeof(double4) + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
+__host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch, int block = WOL_SORT_BLOCK) {
+    return (size_t)ch * block * (sizeof(double4) + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
 }
 
 // The scatter of level 1 for waters [i_begin, i_end) of a frame, cnt[] holding the row cursors in tmp[]:
@@ -317,20 +319,20 @@ __host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch) {
 // atomic = rank inside the row, a scan over the rows) and then written out in that order: a row's waters of the
 // chunk are consecutive lanes writing consecutive addresses.  The next chunk's coordinates are fetched while the
 // current one goes through LDS.  icnt[] must be zero on entry (and is on exit).
-template <typename T, int CH>
+template <typename T, int CH, int SB = WOL_SORT_BLOCK>
 __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base, int64_t atom_stride, int i_begin, int i_end,
                                                      const FrameGrid& g, int* cnt, int* icnt, int* delta, double4* stage,
                                                      int* dest, int* wtot, double4* __restrict__ out) {
-    constexpr int C = CH * WOL_SORT_BLOCK;
+    constexpr int C = CH * SB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
-    const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
+    const int per = (nrow + SB - 1) / SB;
     const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
     double nx_[CH], ny_[CH], nz_[CH];
     if (i_begin >= i_end) return;
 #pragma unroll
     for (int u = 0; u < CH; ++u) {   // (clamped, unconditional loads: see wol_sort_rows_count)
-        const int i = min(i_begin + u * WOL_SORT_BLOCK + tid, i_end - 1);
+        const int i = min(i_begin + u * SB + tid, i_end - 1);
         const T* p = base + (int64_t)i * atom_stride;
         nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
     }
@@ -343,13 +345,13 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
         for (int u = 0; u < CH; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int i = min(c0 + C + u * WOL_SORT_BLOCK + tid, i_end - 1);
+            const int i = min(c0 + C + u * SB + tid, i_end - 1);
             const T* p = base + (int64_t)i * atom_stride;
             nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            const int i = c0 + u * WOL_SORT_BLOCK + tid;
+            const int i = c0 + u * SB + tid;
             row[u] = -1;
             if (i < i_end) {
                 row[u] = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
@@ -386,7 +388,7 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
                 const int k = icnt[row[u]] + lr[u];
                 double4 v;
                 v.x = x[u]; v.y = y[u]; v.z = z[u];
-                v.w = __longlong_as_double((long long)(c0 + u * WOL_SORT_BLOCK + tid));
+                v.w = __longlong_as_double((long long)(c0 + u * SB + tid));
                 stage[k] = v;
                 dest[k] = k + delta[row[u]];
             }
@@ -394,7 +396,7 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
         // (4) out, in staged order; the owners clear the chunk counters for the next round
 #pragma unroll
         for (int u = 0; u < CH; ++u) {   // (a fixed number of stores per chunk: the wait for the next chunk's
-            const int k = tid + u * WOL_SORT_BLOCK;   //  coordinates, fetched before them, need not drain them)
+            const int k = tid + u * SB;   //  coordinates, fetched before them, need not drain them)
             if (k < cn) out[dest[k]] = stage[k];
         }
         for (int k = sb; k < se; ++k) icnt[k] = 0;
@@ -403,7 +405,7 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
 }
 
 // histogram of the (z, y) cell rows of waters [i_begin, i_end) into cnt[] (LDS, zeroed by the caller)
-template <typename T>
+template <typename T, int SB = WOL_SORT_BLOCK>
 __device__ __forceinline__ void wol_sort_rows_count(const T* __restrict__ base, int64_t atom_stride, int i_begin, int i_end,
                                                     const FrameGrid& g, int* cnt) {
 #ifndef WOL_SORT_U
@@ -411,53 +413,53 @@ __device__ __forceinline__ void wol_sort_rows_count(const T* __restrict__ base, 
 #endif
     constexpr int U = WOL_SORT_U;
     const int tid = threadIdx.x, ny = g.nc[1], nz = g.nc[2];
-    for (int i0 = i_begin + tid; i0 < i_end; i0 += WOL_SORT_BLOCK * U) {
+    for (int i0 = i_begin + tid; i0 < i_end; i0 += SB * U) {
         double y[U], z[U];
         // (loads are unconditional -- the index is clamped -- so the compiler issues all U before the first wait: behind
         //  a per-element `if` it waited for every load on its own, one memory round trip after the other)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u * WOL_SORT_BLOCK, i_end - 1);
+            const int i = min(i0 + u * SB, i_end - 1);
             const T* p = base + (int64_t)i * atom_stride;
             y[u] = (double)p[1]; z[u] = (double)p[2];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (i0 + u * WOL_SORT_BLOCK < i_end)
+            if (i0 + u * SB < i_end)
                 atomicAdd(&cnt[wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr)], 1);
     }
 }
 
 // one block per frame: count, scan, scatter (the batch has enough frames to fill the chip)
-template <typename T>
-__global__ void __launch_bounds__(WOL_SORT_BLOCK)
+template <typename T, int SB, int CH>
+__global__ void __launch_bounds__(SB)
 k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
             double4* __restrict__ tmp, int nrow_cap) {
     extern __shared__ double4 lds_sort_rows[];
-    constexpr int C = WOL_L1_CHUNK * WOL_SORT_BLOCK;
+    constexpr int C = CH * SB;
     double4* stage = lds_sort_rows;                                 // [C] the chunk in row order
     int* dest = reinterpret_cast<int*>(stage + C);                   // [C] its slots in tmp[]
     int* cnt = dest + C;                                             // [nrow + 1] row cursors in tmp[]
     int* icnt = cnt + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
     int* delta = icnt + (nrow_cap + 1);                              // [nrow + 1] cursor - start of the row in this chunk
-    __shared__ int part[WOL_SORT_BLOCK];
-    __shared__ int wtot[WOL_SORT_BLOCK / 64];
+    __shared__ int part[SB];
+    __shared__ int wtot[SB / 64];
     const int f = blockIdx.x, tid = threadIdx.x;
     const FrameGrid& g = grids[f];
     const int nrow = g.nc[1] * g.nc[2];
     const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
-    for (int c = tid; c <= nrow; c += WOL_SORT_BLOCK) { cnt[c] = 0; icnt[c] = 0; }
+    for (int c = tid; c <= nrow; c += SB) { cnt[c] = 0; icnt[c] = 0; }
     __syncthreads();
-    wol_sort_rows_count<T>(base, fv.atom_stride, 0, fv.n, g, cnt);
+    wol_sort_rows_count<T, SB>(base, fv.atom_stride, 0, fv.n, g, cnt);
     __syncthreads();
     // exclusive scan of the row counters in place
-    const int per = (nrow + WOL_SORT_BLOCK - 1) / WOL_SORT_BLOCK;
+    const int per = (nrow + SB - 1) / SB;
     const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
     int s = 0;
     for (int k = sb; k < se; ++k) s += cnt[k];
     part[tid] = s;
     __syncthreads();
-    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
+    for (int off = 1; off < SB; off <<= 1) {
         const int v = (tid >= off) ? part[tid - off] : 0;
         __syncthreads();
         part[tid] += v;
@@ -466,9 +468,9 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     int* ro = row_off + (int64_t)f * ro_stride;
     int run = part[tid] - s;
     for (int k = sb; k < se; ++k) { const int v = cnt[k]; cnt[k] = run; ro[k] = run; run += v; }
-    if (tid == WOL_SORT_BLOCK - 1) ro[nrow] = part[WOL_SORT_BLOCK - 1];
+    if (tid == SB - 1) ro[nrow] = part[SB - 1];
     __syncthreads();
-    wol_sort_rows_chunks<T, WOL_L1_CHUNK>(base, fv.atom_stride, 0, fv.n, g, cnt, icnt, delta, stage, dest, wtot,
+    wol_sort_rows_chunks<T, CH, SB>(base, fv.atom_stride, 0, fv.n, g, cnt, icnt, delta, stage, dest, wtot,
                                           tmp + (int64_t)f * fv.n);
 }
 

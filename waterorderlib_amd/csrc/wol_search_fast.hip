@@ -78,6 +78,7 @@ struct FastArgs {
     const int* level;       // [F] density level picked by k_pick_level (index into FrameGrid::lev_*)
     int4* prop;             // [F][n] by sorted slot: sorted slots of the four proposed neighbours
     int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
+    int* work;              // k_search_rows: eight tile counters (one per XCD, 64 B apart; zeroed by the host) or null = static tile order
     unsigned long long* stamps;  // diagnostic builds only
     int rows;               // 1: proposals come from k_search_rows (x reach counted in fine bins, its own eps)
     const unsigned* cnt4;   // per cell: populations of its four fine x bins as bytes (k_sort_in_row); k_search_rows only

@@ -107,7 +107,7 @@ k_search_rows(FastArgs a) {
     __shared__ int rpre[WOL_ROWS_MAXROWS + 1];                   // staged waters before the row
     __shared__ int tbase[WOL_ROWS_MAXTRIP + 1];                  // first entry of the triple (even)
     __shared__ int qrow[WOL_ROWS_MAXRY + 2];                     // own rows -> first query number
-    __shared__ int s_flag;
+    __shared__ int s_flag, s_next;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     constexpr int NW = WOL_ROWS_BLOCK / 64;
@@ -142,9 +142,29 @@ k_search_rows(FastArgs a) {
     int nx = 1, ny = 1, nz = 1, gsx = 1, gry = 1, gntx = 1, ntxy = 1, cell_base = 0, eps_units = 0;
     float inv_ntxy = 1.f, inv_gntx = 1.f, fxs = 0.f, fys = 0.f, fzs = 0.f, eps_a = 0.f, eps_b = 0.f;
     int nt_f = tiles_of(f);
+    // Tile order.  Static (a.work == null): block b walks tiles b, b + grid, ... of its XCD's frames.  Dynamic: the blocks
+    // of an XCD draw (frame, tile) numbers from that XCD's counter -- a block that starts late (the kernel shares the
+    // CUs with the sort of the next batch) or runs on a busier CU then simply takes fewer tiles.  The next number is
+    // drawn while the current tile is being worked on.
+    const bool dyn = a.work != nullptr;
+    int* __restrict__ ctr = dyn ? a.work + (aff ? 16 * (int)(blockIdx.x & 7) : 0) : nullptr;
+    int w_next = 0, w_base = 0;   // next number drawn; first number of frame f (the numbers run through the XCD's frames)
+    if (dyn) {
+        if (tid == 0) s_next = atomicAdd(ctr, 1);
+        __syncthreads();
+        w_next = s_next;
+    }
     for (;; tile += tstep) {
-        while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
-        if (f >= a.F) break;
+        if (dyn) {
+            const int w = __builtin_amdgcn_readfirstlane(w_next);
+            while (f < a.F && w >= w_base + nt_f) { w_base += nt_f; f += fstep; nt_f = tiles_of(f); }
+            if (f >= a.F) break;
+            tile = w - w_base;
+            if (tid == 0) w_next = atomicAdd(ctr, 1);   // (in flight until the end of this tile)
+        } else {
+            while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
+            if (f >= a.F) break;
+        }
         if (f != f_cur) {
             const FrameGrid& g = a.grids[f];
             const int lev = a.level[f];
@@ -440,5 +460,10 @@ k_search_rows(FastArgs a) {
             }
         }
         WOL_STAMP(5);
+        if (dyn) {
+            if (tid == 0) s_next = w_next;
+            __syncthreads();
+            w_next = s_next;
+        }
     }
 }
