@@ -510,3 +510,39 @@ def test_overlapped_batches_equal_the_serial_run(stages):
     q0 = wp.getOrderParamq(xyz[0], xyz[0], boxes[0], ctx=ctx)
     np.testing.assert_allclose(q0, ref.q[0].cpu().numpy(), rtol=0, atol=Q_TOL)
     ctx.close(); ref_ctx.close()
+
+
+@pytest.mark.parametrize("variant", ["rows512", "rows768", "tiles3d"])
+def test_waters_almost_on_top_of_each_other(wp_mod, oracle, variant):
+    """two waters a thousandth of an Angstrom apart (overlapping atoms in a broken input, or random test points): the
+    squared distance rounds to key 0 in the proposal kernel, like the water's own record -- which must therefore be told
+    apart by its position in the tile, not by its distance (found by tools/soak_random.py seed 321: the near twin was
+    dropped with the water itself and both got a wrong 4th neighbour).  Exact duplicates (distance 0, which the
+    reference's lowCut < d test excludes) included."""
+    from waterorderlib_amd import _lib, synth
+    n = 6000
+    xyz, boxes = synth.water_frames(n, 1, seed=29)
+    pos, box = xyz[0].copy(), boxes[0]
+    rng = np.random.default_rng(29)
+    picks = rng.permutation(n)[:120].reshape(60, 2)
+    for k, (w, v) in enumerate(picks):
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        delta = 0.0 if k < 6 else 10.0 ** rng.uniform(-6, -1.7)      # 1e-6 ... 0.02 A
+        pos[v] = pos[w] + delta * u + (rng.integers(-1, 2, size=3) * box if k % 3 == 0 else 0.0)
+    # three on one spot, and a pair straddling a cell wall
+    pos[picks[10, 1]] = pos[picks[11, 0]] + 1e-3
+    q_o, idx_o, dist_o, ang_o = oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
+    ctx = _lib.Context(0)
+    ctx.set_option("path", 3)
+    ctx.set_option("search_rows", 0 if variant == "tiles3d" else 1)
+    if variant != "tiles3d":
+        ctx.set_option("rows_block", int(variant[4:]))
+    q, idx, dist, ang = wp_mod.getOrderParamq(pos, pos, box, full=True, ctx=ctx)
+    assert np.array_equal(idx, idx_o) and np.array_equal(dist, dist_o, equal_nan=True)
+    np.testing.assert_allclose(q, q_o, rtol=0, atol=Q_TOL)
+    frames = np.stack([pos, pos[::-1].copy()])
+    from waterorderlib_amd import engine
+    res = engine.tet_order_traj(frames, np.stack([box, box]), ctx=ctx)
+    mean, var, qh, dh = oracle.tet_order_traj(frames, np.stack([box, box]))
+    assert np.array_equal(res.qhist, qh) and np.array_equal(res.dhist, dh)
+    ctx.close()

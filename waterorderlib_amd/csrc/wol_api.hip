@@ -375,7 +375,8 @@ bool make_grid(const double* box, int n, double cell_width, double high, FrameGr
             const double slope = 2.0 * 2.0 * std::sqrt(ux * ux + uy * uy + uz * uz);
             g->row_eps_a = (float)(1.25 * slope);
             g->row_eps_b = (float)(1.25 * 1.5 + 2.0);
-            g->row_eps_units = (int)std::ceil((slope * (rmax * g->scale) + 1.5) * 1.25) + 2;
+            // (+ 1: the row kernel's keys are d2 (1 - 2^-20), so that the clamped maximum lands on the saturated key)
+            g->row_eps_units = (int)std::ceil((slope * (rmax * g->scale) + 1.5) * 1.25) + 3;
         }
     }
     return true;

@@ -17,8 +17,8 @@
 //            to its bin wall, against nine spans of three whole cells before -- 25 % fewer candidates,
 //            and three trip counts (wave maxima) per water instead of nine.
 //
-// Self-exclusion costs nothing: the bias of the fixed-point conversion is 2^23 - 1, so the water's own
-// record (d2 = 0) leaves the [2^23, 2^24) binade and its key reads as saturated; every other key is d2 - 1.
+// The water's own record is left out by its position in the own triple (wol_rows_span), never by its distance: a
+// second water at (nearly) the same place is a neighbour like any other.
 #pragma once
 
 // Two instantiations: 512 threads / 1280 staged pairs (49 KiB of LDS, three blocks per CU) and 768 threads / 1920
@@ -51,17 +51,41 @@
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
 #endif
 
-// one window of candidate pairs against the lane's water (cf. wol_fast_span; bias 2^23 - 1)
+// one candidate pair against the lane's water: two keys = squared distance in key units << 12 | entry number.
+// Coordinates are staged in units of sqrt(2^-20 key range), so d^2 comes out in [0, 1] and saturates through the CLAMP
+// modifier of its last fma; one more packed fma (x (2^20 - 1) + 2^23) turns it into the float whose mantissa IS the
+// integer key (0 .. 2^20 - 1 = saturated).
 // Records are split in two arrays of 16-byte halves, A = (x0, x1, y0, y1) and B = (z0, z1, id0, id1) per pair:
 // a ds_read_b128 is served in groups of 16 lanes that conflict on (address / 16) mod 16, and consecutive pairs of
 // one array fall on consecutive classes (interleaved 32-byte records would use every other class only).
 template <int B_OFF>   // byte offset of array B behind array A
-__device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes, int pb, int np, int dummy_off,
-                                              wol_f2 xi, wol_f2 yi, wol_f2 zi, unsigned tmaxbits, unsigned& k0,
+__device__ __forceinline__ void wol_rows_pair_keys(const char* __restrict__ rec_bytes, int off, wol_f2 xi, wol_f2 yi, wol_f2 zi,
+                                                   unsigned& key0, unsigned& key1) {
+    const float4 a = *reinterpret_cast<const float4*>(rec_bytes + off);
+    const float4 b = *reinterpret_cast<const float4*>(rec_bytes + off + B_OFF);
+    const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
+    wol_f2 u = dx * dx, uc, tt;
+    u = __builtin_elementwise_fma(dy, dy, u);
+    asm("v_pk_fma_f32 %0, %1, %1, %2 clamp" : "=v"(uc) : "v"(dz), "v"(u));            // min(d^2, 1)
+    tt = __builtin_elementwise_fma(uc, (wol_f2){1048575.0f, 1048575.0f}, (wol_f2){8388608.0f, 8388608.0f});
+    key0 = __builtin_amdgcn_alignbit(__float_as_uint(tt.x), __float_as_uint(b.z), WOL_SLOT_BITS);
+    key1 = __builtin_amdgcn_alignbit(__float_as_uint(tt.y), __float_as_uint(b.w), WOL_SLOT_BITS);
+}
+
+// One window [pb, pb + np) of candidate pairs against the lane's water.  The pair holding the water's own record (byte
+// offset self_off; -1 in the other triples' windows) is left out -- by POSITION, not by its distance: a second water
+// within a hundredth of an Angstrom must stay a candidate (its key rounds to 0 like the water's own would) -- and is
+// dealt with by the caller.
+// Issue cost on gfx950 (tools/valu_probe.hip, profiles/r02_valu_issue_rates.txt): min / max / med3, shifts, compares,
+// selects and the packed fp32 forms hold a SIMD for 4 cycles per wave64 instruction, plain fp32 add / mul / fma and
+// integer add / and for 2.  So lanes past their window are masked off (v_cmp feeding EXEC) instead of being redirected to
+// a dummy pair (v_cmp + v_cndmask).  (Measured and dropped: every lane sweeping the wave's trip count T inside its triple
+// -- a superset of its window, no bounds test -- is slower, 1.41 against 1.38 ms: the LDS then serves 64 lanes in every
+// iteration.)
+template <int B_OFF>
+__device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes, int pb, int np, int self_off,
+                                              wol_f2 xi, wol_f2 yi, wol_f2 zi, unsigned& k0,
                                               unsigned& k1, unsigned& k2, unsigned& k3, unsigned& k4) {
-    const wol_f2 bias = {8388607.0f, 8388607.0f};
-    int off = pb * 16;
-    const int end = (pb + np) * 16;
     // wave-uniform trip count = the longest window of the wave: a DPP reduction (shifts inside the rows of 16, two
     // row broadcasts, lane 63 holds the maximum) instead of six LDS-permute round trips; np >= 0 and all 64 lanes active
     int m = np;
@@ -72,24 +96,12 @@ __device__ __forceinline__ void wol_rows_span(const char* __restrict__ rec_bytes
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x142, 0xa, 0xf, false));  // row_bcast:15
     m = max(m, __builtin_amdgcn_update_dpp(0, m, 0x143, 0xc, 0xf, false));  // row_bcast:31
     const int T = __builtin_amdgcn_readlane(m, 63);
-    // Issue cost on gfx950 (tools/valu_probe.hip, profiles/r02_valu_issue_rates.txt): min / max / med3, shifts, compares,
-    // selects and the packed fp32 forms hold a SIMD for 4 cycles per wave64 instruction, plain fp32 add / mul / fma and
-    // integer add / and for 2.  So: lanes past their window are masked off (one v_cmp feeding EXEC) instead of being
-    // redirected to a dummy pair (v_cmp + v_cndmask), and the squared distance is saturated by the CLAMP modifier of its
-    // last fma -- coordinates are staged in units of sqrt(2^-20 key units), so d^2 comes out in [0, 1] -- followed by one
-    // packed fma that turns it into the fixed-point mantissa (d^2 * 2^20 + 2^23 - 1), instead of two v_min_u32.
-    (void)dummy_off; (void)tmaxbits;
+    int off = pb * 16;
+    const int end = (pb + np) * 16;
     for (int t = 0; t < T; ++t, off += 16) {
-        if (off < end) {
-            const float4 a = *reinterpret_cast<const float4*>(rec_bytes + off);
-            const float4 b = *reinterpret_cast<const float4*>(rec_bytes + off + B_OFF);
-            const wol_f2 dx = (wol_f2){a.x, a.y} - xi, dy = (wol_f2){a.z, a.w} - yi, dz = (wol_f2){b.x, b.y} - zi;
-            wol_f2 u = dx * dx, uc, tt;
-            u = __builtin_elementwise_fma(dy, dy, u);
-            asm("v_pk_fma_f32 %0, %1, %1, %2 clamp" : "=v"(uc) : "v"(dz), "v"(u));            // min(d^2, 1)
-            tt = __builtin_elementwise_fma(uc, (wol_f2){1048576.0f, 1048576.0f}, bias);
-            const unsigned key0 = __builtin_amdgcn_alignbit(__float_as_uint(tt.x), __float_as_uint(b.z), WOL_SLOT_BITS);
-            const unsigned key1 = __builtin_amdgcn_alignbit(__float_as_uint(tt.y), __float_as_uint(b.w), WOL_SLOT_BITS);
+        if (off < end && off != self_off) {
+            unsigned key0, key1;
+            wol_rows_pair_keys<B_OFF>(rec_bytes, off, xi, yi, zi, key0, key1);
             wol_top5_insert(key0, k0, k1, k2, k3, k4);
             wol_top5_insert(key1, k0, k1, k2, k3, k4);
         }
@@ -314,7 +326,6 @@ k_search_rows(FastArgs a) {
         const bool overflow = s_flag != 0;
         const int total_e = tbase[ntrip];
         WOL_STAMP(1);
-        const int dummy_p = (total_e >> 1) + WOL_ROWS_PADP - 2;
         // ---- phase 2: every water to its place, ONE pass: entry = first entry of the triple's bin + the waters of the rows
         //      below in that bin + its rank inside the bin.  A wave takes whole rows; the fetch of the next 64 waters is in
         //      flight while the current 64 are placed. ----
@@ -407,13 +418,18 @@ k_search_rows(FastArgs a) {
                 const unsigned mtag = __float_as_uint(me.w);
                 const int sc = (int)(mtag & 0xFFu) - x0 + 1;
                 const int b = sc * WOL_XSUB + (int)((mtag >> 8) & 3u);
+                // the water's own entry in its triple, as the placement pass computed it (centre z row: the z-1 row's
+                // waters of the bin come first)
+                const int e_self = tbase[j + 1] + (int)bins16[2 * (j + 1) * nbw + b] +
+                                   (int)reinterpret_cast<const unsigned char*>(obins)[(j + 1) * nbw * 4 + 8 * sc + (int)((mtag >> 8) & 3u)] +
+                                   (int)(mtag >> 10);
+                const int self_off = (e_self >> 1) * 16;
                 const float mx = __builtin_fmaf(me.x, WOL_ROWS_CSCALE, ((float)sc - xc) * fxs);
                 const float my = __builtin_fmaf(me.y, WOL_ROWS_CSCALE, ((float)(j + 1) - yc) * fys), mz = me.z * WOL_ROWS_CSCALE;
                 const wol_f2 xi = {mx, mx}, yi = {my, my}, zi = {mz, mz};
-                const unsigned tmaxbits = 0u;
                 unsigned k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu, k3 = 0xFFFFFFFFu, k4 = 0xFFFFFFFFu;
-                // the three windows as (pairs << 16 | first pair); each lane sweeps its longest first: the loops' trip
-                // counts are wave maxima, and maxima of sorted lengths add up to less (38.3 instead of 40.5 pairs)
+                // the three windows as (pairs << 16 | triple << 12 | first pair); each lane sweeps its longest first: the
+                // loops' trip counts are wave maxima, and maxima of sorted lengths add up to less (38.3 instead of 40.5 pairs)
                 unsigned win[3];
 #pragma unroll
                 for (int dt = 0; dt < 3; ++dt) {
@@ -421,7 +437,7 @@ k_search_rows(FastArgs a) {
                     const unsigned short* __restrict__ bt = bins16 + 2 * t * nbw;
                     const int lo = tbase[t] + (int)bt[b - WOL_XSUB], hi = tbase[t] + (int)bt[b + WOL_XSUB + 1];
                     const int pb = lo >> 1, pe = live ? (hi + 1) >> 1 : pb;
-                    win[dt] = ((unsigned)(pe - pb) << 16) | (unsigned)pb;
+                    win[dt] = ((unsigned)(pe - pb) << 16) | ((unsigned)dt << 12) | (unsigned)pb;
                 }
 #ifndef WOL_EXP_NO_WINSORT
                 {
@@ -435,10 +451,21 @@ k_search_rows(FastArgs a) {
 #ifdef WOL_EXP_NO_SWEEP   // ablation build: timing only, results are wrong
                     k0 ^= win[dt];
 #else
-                    wol_rows_span<16 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)>(reinterpret_cast<const char*>(rec), (int)(win[dt] & 0xFFFFu), (int)(win[dt] >> 16), dummy_p * 16,
-                                  xi, yi, zi, tmaxbits, k0, k1, k2, k3, k4);
+                    const int wt = (int)((win[dt] >> 12) & 3u);     // which triple this window lies in
+                    wol_rows_span<16 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)>(reinterpret_cast<const char*>(rec), (int)(win[dt] & 0xFFFu), (int)(win[dt] >> 16),
+                                  wt == 1 ? self_off : -1,
+                                  xi, yi, zi, k0, k1, k2, k3, k4);
 #endif
                 }
+#ifndef WOL_EXP_NO_SWEEP
+#ifndef WOL_EXP_NO_PARTNER
+                {   // the other water of the own pair (the sweeps skipped the pair as a whole)
+                    unsigned key0, key1;
+                    wol_rows_pair_keys<16 * (WOL_ROWS_CAPP + WOL_ROWS_PADP)>(reinterpret_cast<const char*>(rec), self_off, xi, yi, zi, key0, key1);
+                    wol_top5_insert((e_self & 1) ? key0 : key1, k0, k1, k2, k3, k4);
+                }
+#endif
+#endif
                 const unsigned d3 = k3 >> WOL_ID_BITS, d4 = k4 >> WOL_ID_BITS;
                 const unsigned sat = (1u << (32 - WOL_ID_BITS)) - 1u - (unsigned)eps_units;
                 // the proposal stands when the 5th key is separated from the 4th by more than both keys' fp32 error
@@ -451,7 +478,7 @@ k_search_rows(FastArgs a) {
                         return (int)(__float_as_uint(recg[(e >> 1) * 4 + 2 + (e & 1)]) & sm);
                     };
                     prop.x = slot_of(k0); prop.y = slot_of(k1); prop.z = slot_of(k2); prop.w = slot_of(k3);
-                    kd3 = (int)d3 + 1;  // keys are d2 - 1
+                    kd3 = (int)d3;
                 }
             }
             if (live) {
