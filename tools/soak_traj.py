@@ -37,7 +37,10 @@ for seed in range(first, first + count):
     hi = float(rng.choice([10.0, 10.0, 3.5, 5.0]))
     lo = float(rng.choice([0.0, 0.0, 2.7]))
     want_q = bool(seed % 2)
-    oxy = np.ascontiguousarray(frames[:, ::len_wat])
+    f32 = seed % 7 == 3                                   # float32 storage: promoted exactly, same fp64 arithmetic
+    if f32: frames = frames.astype(np.float32)
+    if seed % 11 == 5: frames = frames + (1000.0 * boxes[:, None, :]).astype(frames.dtype)    # far outside the box
+    oxy = np.ascontiguousarray(frames[:, ::len_wat]).astype(np.float64)
     m_o, v_o, qh_o, dh_o = wol_oracle.tet_order_traj(oxy, boxes, lowCut=lo, highCut=hi, cells=True)
     for rows in (1, 0):
         for dev in (False, True):
@@ -49,14 +52,14 @@ for seed in range(first, first + count):
                   np.allclose(g(r.mean), m_o, rtol=0, atol=1e-13) and np.allclose(g(r.var), v_o, rtol=0, atol=1e-13))
             if want_q and ok:
                 # per-water q agrees with the frame means it was reduced to
-                ok = np.allclose(g(r.q).mean(axis=1), m_o, rtol=0, atol=1e-12)
+                ok = np.allclose(g(r.q).astype(np.float64).mean(axis=1), m_o, rtol=0, atol=1e-6 if f32 else 1e-12)
             if not ok:
                 bad += 1
                 print("MISMATCH seed %d rows %d dev %d: qhist %d dhist %d mean %.2e" % (
                     seed, rows, dev, int(np.abs(g(r.qhist) - qh_o).sum()), int(np.abs(g(r.dhist) - dh_o).sum()),
                     float(np.abs(g(r.mean) - m_o).max())))
             c.close()
-    print("seed %3d T %3d n %5d len_wat %d npt %d cuts %.1f-%.1f q %d %s" % (seed, T, n, len_wat, npt, lo, hi, want_q,
+    print("seed %3d T %3d n %5d len_wat %d npt %d f32 %d cuts %.1f-%.1f q %d %s" % (seed, T, n, len_wat, npt, f32, lo, hi, want_q,
                                                                           "ok" if bad == 0 else ""), flush=True)
 print("mismatching runs:", bad)
 sys.exit(1 if bad else 0)
