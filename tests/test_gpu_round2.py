@@ -546,3 +546,29 @@ def test_waters_almost_on_top_of_each_other(wp_mod, oracle, variant):
     mean, var, qh, dh = oracle.tet_order_traj(frames, np.stack([box, box]))
     assert np.array_equal(res.qhist, qh) and np.array_equal(res.dhist, dh)
     ctx.close()
+
+
+def test_trajectory_mode_q_where_its_shortcut_is_ill_conditioned(oracle):
+    """the trajectory mode forms q from the minimum-image vectors d themselves, the reference from (c + d) - c: they differ
+    by ~4 ulp(c) / |d|, far below the tolerance for a liquid in its box -- not for frames that sit a hundred thousand box
+    lengths from the origin, nor next to a neighbour a few thousandths of an Angstrom away.  Those waters take the exact chain:
+    per-water q stays within tolerance, the histograms stay identical (found by tools/soak_traj.py seeds 1017, 2205)."""
+    from waterorderlib_amd import _lib, engine, synth
+    n = 5000
+    xyz, boxes = synth.water_frames(n, 3, seed=31)
+    far = xyz + 1.0e5 * boxes[:, None, :] * np.array([1.0, -1.0, 1.0])    # (|dq| reached 1.5e-10 here, 2e-9 at 1e7)
+    twins = xyz.copy()
+    rng = np.random.default_rng(31)
+    for f in range(3):
+        for w, v in rng.permutation(n)[:80].reshape(40, 2):
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            twins[f, v] = twins[f, w] + 10.0 ** rng.uniform(-6, -1.5) * u
+    ctx = _lib.Context(0)
+    for frames in (far, twins):
+        res = engine.tet_order_traj(frames, boxes, want_q=True, ctx=ctx)
+        mean, var, qh, dh = oracle.tet_order_traj(frames, boxes)
+        assert np.array_equal(res.qhist, qh) and np.array_equal(res.dhist, dh)
+        np.testing.assert_allclose(res.mean, mean, rtol=0, atol=1e-13)
+        for f in range(3):
+            np.testing.assert_allclose(res.q[f], oracle.getOrderParamq(frames[f], frames[f], boxes[f], cells=True), rtol=0, atol=Q_TOL)
+    ctx.close()

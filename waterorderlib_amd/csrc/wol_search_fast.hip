@@ -610,7 +610,11 @@ k_finish_fast(FastArgs a) {
                 const double dy = ey - g.box.L[1] * rint(ey * g.box.ib[1]);
                 const double dz = ez - g.box.L[2] * rint(ez * g.box.ib[2]);
                 const double d2 = wol_sumsq(dx, dy, dz);
-                all_in = all_in && (d2 > 0.0) && (d2 <= a.highsq);
+                // q from d instead of (c + d) - c is off by ~ 4 ulp(c) / d: where that could pass 4e-13 (coordinates
+                // thousands of box lengths from the origin, or a neighbour a few thousandths of an Angstrom away: d below
+                // a thousandth of the coordinates' magnitude) the reference's chain is evaluated, on the exact path
+                const double dlow = cguard * 1e11;
+                all_in = all_in && (d2 > dlow * dlow) && (d2 <= a.highsq);
                 const double rn = rsqrt(d2);
                 const double dist = d2 * rn;
                 dmax = fmax(dmax, dist);
