@@ -572,3 +572,17 @@ def test_trajectory_mode_q_where_its_shortcut_is_ill_conditioned(oracle):
         for f in range(3):
             np.testing.assert_allclose(res.q[f], oracle.getOrderParamq(frames[f], frames[f], boxes[f], cells=True), rtol=0, atol=Q_TOL)
     ctx.close()
+
+
+def test_lsi_with_shells_of_hundreds_of_waters(wp_mod, oracle):
+    """getLSI sorts the shell's distances in a per-water scratch row sized for a liquid; a droplet of random points with
+    hundreds of neighbours inside highCut makes the library size the rows from the kernel's own report and run again
+    (it used to refuse such input; tools/soak_shell.py seed 21)"""
+    rng = np.random.default_rng(41)
+    box = np.array([40.0, 37.0, 43.0])
+    pos = rng.random((3000, 3)) * box
+    pos[:900] = box * 0.5 + rng.normal(0.0, 2.0, size=(900, 3))
+    li, ln = wp_mod.getLSI(pos, pos, box, 0.0, 3.7)
+    ri, rn = oracle.getLSI(pos, pos, box, 0.0, 3.7)
+    assert rn.max() > 200 and np.array_equal(ln, rn) and li.shape == ri.shape
+    np.testing.assert_allclose(li, ri, rtol=0, atol=1e-12)

@@ -1512,23 +1512,33 @@ int wol_lsi_frame_t(wol_ctx* c, const void* pos, int n, const void* sub, int ns,
     WOL_TRY(shell_setup(c, RealSrc{pos, dtype, mem}, n, RealSrc{sub, dtype, mem}, ns, box, high2, &sa));
     sa.lowsq = lowcut * lowcut;
     sa.highsq = highcut * highcut;
-    WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)WOL_LSI_CAP * (size_t)ns));
     WOL_TRY(c->out_stage.ensure(sizeof(double) * 2 * (size_t)ns));
     WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
-    HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
     double* d_lsi = c->out_stage.as<double>();
     double* d_num = d_lsi + ns;
-    hipLaunchKernelGGL(k_lsi, dim3((ns + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream, sa,
-                       high2 * high2, c->qbuf.as<double>(), d_lsi, d_num, c->slow_count.as<int>());
-    std::vector<double> hlsi((size_t)ns);   // the count of valid entries (len(lsiVals), wp:308) is a host value
     int over = 0;
+    // the shell's distances are sorted in a per-water scratch row: a first attempt with room for a liquid's shell many
+    // times over; a water with more neighbours than that (a dense cluster, a long highcut) reports how many it has and
+    // the kernel runs once more with rows of that length
+    for (int cap = WOL_LSI_CAP, attempt = 0; attempt < 2; ++attempt) {
+        WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)cap * (size_t)ns));
+        HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+        hipLaunchKernelGGL(k_lsi, dim3((ns + WOL_BLOCK - 1) / WOL_BLOCK), dim3(WOL_BLOCK), 0, c->stream, sa,
+                           high2 * high2, c->qbuf.as<double>(), cap, d_lsi, d_num, c->slow_count.as<int>());
+        HIP_TRY(hipMemcpyAsync(&over, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!over) break;
+        if ((size_t)over * (size_t)ns * sizeof(double) > ((size_t)16 << 30))
+            return fail(WOL_ERR_NOMEM, "lsi_frame: a water has %d neighbours inside highcut; %d such rows do not fit", over - 2, ns);
+        cap = over;
+    }
+    std::vector<double> hlsi((size_t)ns);   // the count of valid entries (len(lsiVals), wp:308) is a host value
     WOL_TRY(deliver_f64(c, d_lsi, lsi_full, (size_t)ns, dtype, mem, 0));
     WOL_TRY(deliver_f64(c, d_num, num_lsi, (size_t)ns, dtype, mem, 1));
     HIP_TRY(hipMemcpyAsync(hlsi.data(), d_lsi, sizeof(double) * (size_t)ns, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&over, c->slow_count.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    if (over) return fail(WOL_ERR_INVALID, "lsi_frame: a water has more than %d neighbours inside highcut", WOL_LSI_CAP - 2);
+    if (over) return fail(WOL_ERR_INVALID, "lsi_frame: shell larger than reported (%d)", over);
     int64_t nv = 0;
     for (int i = 0; i < ns; ++i) nv += (hlsi[(size_t)i] == hlsi[(size_t)i]) ? 1 : 0;
     if (nvalid) *nvalid = nv;

@@ -182,17 +182,18 @@ __device__ __forceinline__ double wol_np_sum_small(const double* v, int n) {
     return res;
 }
 
-#define WOL_LSI_CAP 96  // shell + 1 distances per water held in scratch (the 3.7 A shell has ~5-8)
+#define WOL_LSI_CAP 96  // shell + 1 distances per water held in scratch at the first attempt (the 3.7 A shell has ~5-8);
+                        // a denser shell reports its size and the host launches again with room for it
 
 __global__ void __launch_bounds__(WOL_BLOCK)
-k_lsi(ShellArgs a, double high2sq, double* __restrict__ scratch, double* __restrict__ lsi_full,
+k_lsi(ShellArgs a, double high2sq, double* __restrict__ scratch, int cap, double* __restrict__ lsi_full,
       double* __restrict__ num_lsi, int* __restrict__ overflow) {
     const int q = blockIdx.x * WOL_BLOCK + threadIdx.x;
     if (q >= a.ns) return;
     double c[3];
     int row;
     wol_shell_query(a, q, c, &row);
-    double* __restrict__ dist = scratch + (int64_t)q * WOL_LSI_CAP;
+    double* __restrict__ dist = scratch + (int64_t)q * cap;
     const FrameGrid& g = *a.grid;
     int k = 0;
     bool have_next = false;
@@ -200,7 +201,7 @@ k_lsi(ShellArgs a, double high2sq, double* __restrict__ scratch, double* __restr
     int next_idx = 0x7fffffff;
     wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
         if (d2 > a.lowsq && d2 <= a.highsq) {
-            if (k < WOL_LSI_CAP - 1) dist[k] = sqrt(d2);  // lsiDists, waterlib.f90:916
+            if (k < cap - 1) dist[k] = sqrt(d2);  // lsiDists, waterlib.f90:916
             ++k;
         }
         if (d2 > a.highsq && d2 <= high2sq) {
@@ -218,8 +219,8 @@ k_lsi(ShellArgs a, double high2sq, double* __restrict__ scratch, double* __restr
     (void)g;
     double res = __builtin_nan("");
     double cnt = 0.0;
-    if (k >= WOL_LSI_CAP - 1) {
-        atomicExch(overflow, 1);
+    if (k >= cap - 1) {
+        atomicMax(overflow, k + 2);   // the capacity this water needs
     } else if (k > 1 && have_next) {
         dist[k] = sqrt(next_d2);
         const int m = k + 1;
