@@ -83,10 +83,12 @@ def _traj_device(frames, boxes, lowCut, highCut, len_wat, qbins, dbins, dbinwidt
     dev = frames.device
     ctx = ctx or _lib.default_context(dev.index if dev.index is not None else torch.cuda.current_device())
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    mean = torch.zeros(T, dtype=torch.float64, device=dev)
-    var = torch.zeros(T, dtype=torch.float64, device=dev)
-    qh = torch.zeros(qbins, dtype=torch.int64, device=dev)
-    dh = torch.zeros(dbins, dtype=torch.int64, device=dev) if want_dhist else None
+    # the library writes mean / var of every frame and ADDS to the histograms: one zero-fill for both histograms
+    stats = torch.zeros((2, T), dtype=torch.float64, device=dev) if not (T and n) else torch.empty((2, T), dtype=torch.float64, device=dev)
+    mean, var = stats[0], stats[1]
+    hists = torch.zeros(qbins + (dbins if want_dhist else 0), dtype=torch.int64, device=dev)
+    qh = hists[:qbins]
+    dh = hists[qbins:] if want_dhist else None
     q = torch.empty((T, n), dtype=frames.dtype, device=dev) if want_q else None
     fn = _lib.load().wol_q_traj_f32 if frames.dtype == torch.float32 else _lib.load().wol_q_traj
     vp = C.c_void_p
