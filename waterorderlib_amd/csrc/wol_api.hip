@@ -100,6 +100,7 @@ struct wol_ctx {
         DevBuf sorted, sorted32, cells, grids, level, cnt4, prop, prop_key, work;
         hipEvent_t sorted_ev = nullptr;    // recorded on the sort stream when the set is filled
         hipEvent_t searched_ev = nullptr;  // recorded on the search stream when the proposals are written
+        hipEvent_t rows_ev = nullptr, level_ev = nullptr;   // first sort level done / density level picked (beside the second level)
         hipEvent_t free_ev = nullptr;      // recorded on `stream` when its last reader is done
         bool used = false;
     } sets[WOL_NSETS];
@@ -493,6 +494,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             HIP_TRY(hipEventCreateWithFlags(&S.sorted_ev, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&S.searched_ev, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&S.free_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.rows_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&S.level_ev, hipEventDisableTiming));
         }
         hipStream_t ss = c->stream, qs = c->stream;   // the streams of the sort and of the proposal kernel
         if (pipe) {
@@ -528,6 +531,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             c->shell_dirty = false;
         }
         HIP_TRY(hipMemcpyAsync(S.grids.p, gh, sizeof(FrameGrid) * (size_t)F, hipMemcpyHostToDevice, c->grid_stream));
+        // one small control block per batch: the eight tile counters of the proposal kernel (64 B apart), then the
+        // length of the exact list -- zeroed with one fill, out of the kernels' way as well
+        WOL_TRY(S.work.ensure(sizeof(int) * (16 * 8 + 4)));
+        HIP_TRY(hipMemsetAsync(S.work.p, 0, sizeof(int) * (16 * 8 + 4), c->grid_stream));
         HIP_TRY(hipEventRecord(c->grid_ev, c->grid_stream));
         HIP_TRY(hipStreamWaitEvent(ss, c->grid_ev, 0));
         c->grid_copy_pending = true;
@@ -607,6 +614,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             return WOL_OK;
         };
         int P = 1;
+        bool level_early = false;
         if (layer_sort && (5 * F < 3 * c->num_cus || big_rows)) {   // fewer frames than ~0.6 blocks per CU: split them
             P = std::min(64, std::max(1, (2 * c->num_cus + F - 1) / F));          // about two blocks per CU
             P = std::min(P, std::max(1, n / (4 * WOL_SORT_BLOCK)));                  // at least a few chunks each
@@ -655,7 +663,19 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                                        wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
                                        c->sort_tmp.as<double4>(), nrow_max);
             }
+            if (use_fast) {
+                // the density level of every frame needs the rows' populations only: picked on the side stream while the
+                // second level runs (the sort stream waits for it before the row offsets are reused)
+                WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
+                HIP_TRY(hipEventRecord(S.rows_ev, ss));
+                HIP_TRY(hipStreamWaitEvent(c->grid_stream, S.rows_ev, 0));
+                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->grid_stream, S.grids.as<FrameGrid>(), S.cells.as<int>(),
+                                   c->layer_off.as<int>(), ro_stride, S.level.as<int>());
+                HIP_TRY(hipEventRecord(S.level_ev, c->grid_stream));
+                level_early = true;
+            }
             launch_in_row(ro_stride);
+            if (level_early) HIP_TRY(hipStreamWaitEvent(ss, S.level_ev, 0));
         } else if (lds_sort) {
             if (sort_lds > c->sort_lds_set) {
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_frame_lds<T>),
@@ -710,12 +730,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             // waters per cell) is then finished by the exact kernel instead of being certified from whatever the buffer
             // held.  (The row kernel writes a key for every water of every tile it is given, overflowing tiles included.)
             if (!rows_kernel) HIP_TRY(hipMemsetAsync(S.prop_key.p, 0xFF, sizeof(int) * (size_t)F * n, qs));
-            // one small control block per batch: the eight tile counters of the proposal kernel (64 B apart), then the
-            // length of the exact list -- zeroed with one fill
-            WOL_TRY(S.work.ensure(sizeof(int) * (16 * 8 + 4)));
-            HIP_TRY(hipMemsetAsync(S.work.p, 0, sizeof(int) * (16 * 8 + 4), qs));
-            WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
-            hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, S.level.as<int>());
+            if (!level_early) {
+                WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
+                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, (const int*)nullptr, 0, S.level.as<int>());
+            }
             FastArgs fa;
             fa.level = S.level.as<int>();
             fa.grids = a.grids; fa.sorted = a.sorted; fa.sorted32 = s32; fa.cell_start = a.cell_start;
@@ -1150,6 +1168,8 @@ int wol_ctx_destroy(wol_ctx* c) {
                       &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->stamps, &c->scan_tot};
     for (auto& S : c->sets) {
         S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release(); S.prop.release(); S.prop_key.release(); S.work.release();
+        if (S.rows_ev) (void)hipEventDestroy(S.rows_ev);
+        if (S.level_ev) (void)hipEventDestroy(S.level_ev);
         if (S.searched_ev) (void)hipEventDestroy(S.searched_ev);
         if (S.sorted_ev) (void)hipEventDestroy(S.sorted_ev);
         if (S.free_ev) (void)hipEventDestroy(S.free_ev);

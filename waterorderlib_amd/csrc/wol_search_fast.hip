@@ -209,7 +209,8 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
 // average); the first prepared tile shape that fits it is selected.  One block per frame.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WOL_BLOCK)
-k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start, int* __restrict__ level) {
+k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start, const int* __restrict__ row_off,
+             int ro_stride, int* __restrict__ level) {
     __shared__ int rows[12288];
     __shared__ int smax[WOL_BLOCK];
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -217,7 +218,12 @@ k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_s
     const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
     const int* __restrict__ cs = cell_start + g.cell_base;
     const bool ok = g.maxshell >= 0 && nrow <= 12288;
-    if (ok)
+    // waters per (z, y) cell row: from the first sort level's row offsets where it ran (the kernel then runs beside the
+    // second level), else from the finished cell table
+    if (ok && row_off) {
+        const int* __restrict__ ro = row_off + (int64_t)f * ro_stride;
+        for (int r = tid; r < nrow; r += WOL_BLOCK) rows[r] = ro[r + 1] - ro[r];
+    } else if (ok)
         for (int r = tid; r < nrow; r += WOL_BLOCK) rows[r] = cs[(r + 1) * nx] - cs[r * nx];
     __syncthreads();
     // densest window of 4 rows x 2 layers (about the size of a tile; a single row is too noisy)
