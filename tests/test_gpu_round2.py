@@ -586,3 +586,31 @@ def test_lsi_with_shells_of_hundreds_of_waters(wp_mod, oracle):
     ri, rn = oracle.getLSI(pos, pos, box, 0.0, 3.7)
     assert rn.max() > 200 and np.array_equal(ln, rn) and li.shape == ri.shape
     np.testing.assert_allclose(li, ri, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [2500, 7000, 40000, 210000])
+def test_both_forms_of_the_first_sort_level(oracle, n):
+    """the first sort level either sizes row buckets with a counting pass and appends to them (seg_sort = 0) or writes
+    every chunk as it lies in LDS with a table of the rows' starts, from which the second level collects its row
+    (seg_sort = 2: forced; one chunk, a few, 14, and more than 64 chunks -- two rounds of the per-row piece scan).  The
+    order of waters inside a fine bin differs between the two; no result may."""
+    from waterorderlib_amd import _lib, engine, synth
+    T = 3 if n > 100000 else 70
+    xyz, boxes = synth.water_frames(n, 1, seed=37)
+    rng = np.random.default_rng(37)
+    scale = 1.0 + 0.05 * rng.random((T, 3))
+    frames = np.stack([xyz[0][rng.permutation(n)] for _ in range(T)]) * scale[:, None, :]
+    bx = boxes[0][None] * scale
+    out = {}
+    for mode in (0, 2):
+        ctx = _lib.Context(0)
+        ctx.set_option("seg_sort", mode)
+        if T < 64: ctx.set_option("sort_parts", 1)      # (few frames would take the split form of the first level)
+        out[mode] = engine.tet_order_traj(frames, bx, want_q=True, ctx=ctx)
+        ctx.close()
+    a, b = out[0], out[2]
+    assert np.array_equal(a.q, b.q) and np.array_equal(a.qhist, b.qhist) and np.array_equal(a.dhist, b.dhist)
+    assert np.array_equal(a.mean, b.mean) and np.array_equal(a.var, b.var)
+    mean, var, qh, dh = oracle.tet_order_traj(frames, bx)
+    assert np.array_equal(b.qhist, qh) and np.array_equal(b.dhist, dh)
+    np.testing.assert_allclose(b.mean, mean, rtol=0, atol=1e-13)

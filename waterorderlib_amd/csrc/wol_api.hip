@@ -117,9 +117,12 @@ struct wol_ctx {
     int force_rows_block = 0;  // 0 = per batch by lane fill; 512 / 768 = that k_search_rows instantiation (tests, tuning)
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
     int dyn_tiles = 1;       // 1: the proposal kernel's blocks draw their tiles from per-XCD counters (default); 0: static tile order
+    int seg_sort = 1;        // first sort level in its single-pass segment form: 1 = for frames of 8 chunks (24 576 waters) and
+                             // more (smaller frames sort faster through row buckets: their second read comes out of L2), 2 = whenever it applies, 0 = never
     int stages = 2;          // pipe depth of the trajectory path: 2 = sort | proposal + certification, 3 = sort | proposal | certification
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
     SortSet* last_set = nullptr;
+    DevBuf seg_tab;   // segment form of the first sort level: start of every row inside every chunk (16 bit)
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, stamps, scan_tot;
     PinBuf grids_host;
     DevBuf cvt_in, cvt_out[4], xchg, stat_part;
@@ -590,16 +593,17 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             cnt4 = S.cnt4.as<unsigned>();
         }
         if (in_row_stage) WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
+        RowPieces pieces{nullptr, 0, 0, 0};
         auto launch_in_row = [&](int ro_stride) {
             const size_t lds = sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64);
             if ((int64_t)n > 100 * (int64_t)std::max(nrow_all, 1))   // long rows (big boxes): four waters per lane
                 hipLaunchKernelGGL(k_sort_in_row<4>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
                                    c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
-                                   S.sorted.as<double4>(), s32, cnt4, nb_cap);
+                                   S.sorted.as<double4>(), s32, cnt4, nb_cap, pieces);
             else
                 hipLaunchKernelGGL(k_sort_in_row<2>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
                                    c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
-                                   S.sorted.as<double4>(), s32, cnt4, nb_cap);
+                                   S.sorted.as<double4>(), s32, cnt4, nb_cap, pieces);
         };
         // (the cell-level sorts below write into the row buckets when the in-row stage follows them)
         double4* cell_sorted_out = (in_row_stage && !layer_sort) ? c->sort_tmp.as<double4>() : S.sorted.as<double4>();
@@ -628,6 +632,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                 const int lds_a = (int)wol_sort_rows_lds(WOL_L1_MAXROWS, WOL_L1_CHUNK);
                 const int lds_b = (int)wol_sort_rows_lds(WOL_L1_MAXROWS_BIG, WOL_L1_CHUNK_BIG);
                 const int lds_p = (int)wol_sort_rows_lds(WOL_L1_MAXROWS, WOL_L1_CHUNK_PIPE, WOL_L1_BLOCK_PIPE);
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double, WOL_SORT_BLOCK, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<double, WOL_L1_BLOCK_PIPE, WOL_L1_CHUNK_PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_p));
@@ -644,6 +650,15 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                 hipLaunchKernelGGL((k_sort_rows<T, WOL_L1_BLOCK_PIPE, WOL_L1_CHUNK_PIPE>), dim3(F), dim3(WOL_L1_BLOCK_PIPE),
                                    wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_PIPE, WOL_L1_BLOCK_PIPE), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
+            } else if (P == 1 && c->seg_sort && (n + WOL_L1_CHUNK * WOL_SORT_BLOCK - 1) / (WOL_L1_CHUNK * WOL_SORT_BLOCK) <= WOL_SEG_MAXCHUNK &&
+                       (c->seg_sort >= 2 || n >= 8 * WOL_L1_CHUNK * WOL_SORT_BLOCK)) {
+                // single pass: chunks written as they lie in LDS plus a table of the rows' starts inside every chunk
+                const int chunk_waters = WOL_L1_CHUNK * WOL_SORT_BLOCK, nchunk = (n + chunk_waters - 1) / chunk_waters;
+                WOL_TRY(c->seg_tab.ensure(sizeof(unsigned short) * (size_t)F * (size_t)(nrow_max + 1) * nchunk));
+                pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters};
+                hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
+                                   S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
+                                   c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);
             } else if (P == 1) {
                 hipLaunchKernelGGL((k_sort_rows<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
@@ -1165,7 +1180,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     for (auto& ev : c->ev_used) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (auto& ev : c->ev_free) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     DevBuf* bufs[] = {&c->cellid, &c->rank, &c->qbuf, &c->in_stage,
-                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->stamps, &c->scan_tot};
+                      &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->stamps, &c->scan_tot, &c->seg_tab};
     for (auto& S : c->sets) {
         S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release(); S.prop.release(); S.prop_key.release(); S.work.release();
         if (S.rows_ev) (void)hipEventDestroy(S.rows_ev);
@@ -1236,6 +1251,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->sort_parts = (int)value;
     } else if (k == "dyn_tiles") {
         c->dyn_tiles = (int)value;
+    } else if (k == "seg_sort") {
+        c->seg_sort = (int)value;
     } else if (k == "stages") {
         c->stages = (int)value;
     } else if (k == "search_margin") {

@@ -474,6 +474,124 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
                                           tmp + (int64_t)f * fv.n);
 }
 
+// ---------------------------------------------------------------------------------------------
+// First level, single-pass form ("segments"): one block per frame.  The frame is cut into chunks of CH * SB waters; a
+// chunk is ordered by (z, y) cell row inside LDS (returning atomic = rank inside the row, a scan over the rows) and
+// written out AS IT LIES THERE -- one contiguous 32-byte-record stream per block, no read of the frame beforehand to size
+// row buckets -- together with the start of every row inside the chunk (tab[row][chunk], 16 bit).  The second level's
+// wave then collects its row from the frame's chunks (~3 waters of the row in each).  The row totals, summed as the
+// chunks go by, give the rows' places in the final arrays (row_off), as before.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int SB, int CH>
+__global__ void __launch_bounds__(SB)
+k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
+                double4* __restrict__ tmp, unsigned short* __restrict__ tab, int tab_rows, int nchunk_cap, int nrow_cap) {
+    extern __shared__ double4 lds_sort_rows[];
+    constexpr int C = CH * SB;
+    double4* stage = lds_sort_rows;                                  // [C] the chunk in row order
+    int* tot = reinterpret_cast<int*>(stage + C);                    // [nrow + 1] waters of the row so far
+    int* icnt = tot + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
+    __shared__ int part[SB];
+    __shared__ int wtot[SB / 64];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FrameGrid& g = grids[f];
+    const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
+    const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
+    double4* __restrict__ out = tmp + (int64_t)f * fv.n;
+    unsigned short* __restrict__ tb = tab + (int64_t)f * tab_rows * nchunk_cap;
+    const int per = (nrow + SB - 1) / SB;
+    const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
+    for (int c = tid; c <= nrow; c += SB) { tot[c] = 0; icnt[c] = 0; }
+    const int i_end = fv.n;
+    double nx_[CH], ny_[CH], nz_[CH];
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {   // (clamped, unconditional loads: see wol_sort_rows_count)
+        const int i = min(u * SB + tid, i_end - 1);
+        const T* p = base + (int64_t)i * fv.atom_stride;
+        nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
+    }
+    __syncthreads();
+    int chunk = 0;
+    for (int c0 = 0; c0 < i_end; c0 += C, ++chunk) {
+        const int cn = min(C, i_end - c0);
+        double x[CH], y[CH], z[CH];
+        int row[CH], lr[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {   // the next chunk's coordinates travel while this one goes through LDS
+            const int i = min(c0 + C + u * SB + tid, i_end - 1);
+            const T* p = base + (int64_t)i * fv.atom_stride;
+            nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int i = c0 + u * SB + tid;
+            row[u] = -1;
+            if (i < i_end) {
+                row[u] = wol_cell_coord(z[u], g.box.ib[2], nz, nullptr) * ny + wol_cell_coord(y[u], g.box.ib[1], ny, nullptr);
+                lr[u] = atomicAdd(&icnt[row[u]], 1);
+            }
+        }
+        __syncthreads();
+        // starts of the rows inside the chunk (thread t owns rows [sb, se)): into LDS for the placement, into the table
+        // for the second level; the row totals advance
+        int s2 = 0;
+        for (int k = sb; k < se; ++k) s2 += icnt[k];
+        int inc = s2;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += v;
+        }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int before = 0;
+        for (int w2 = 0; w2 < wave; ++w2) before += wtot[w2];
+        int st = before + inc - s2;
+        for (int k = sb; k < se; ++k) {
+            const int v = icnt[k];
+            icnt[k] = st;
+            tb[(int64_t)k * nchunk_cap + chunk] = (unsigned short)st;
+            tot[k] += v;
+            st += v;
+        }
+        if (tid == SB - 1) tb[(int64_t)nrow * nchunk_cap + chunk] = (unsigned short)cn;   // (row nrow: the end of the last row)
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (row[u] >= 0) {
+                double4 v;
+                v.x = x[u]; v.y = y[u]; v.z = z[u];
+                v.w = __longlong_as_double((long long)(c0 + u * SB + tid));
+                stage[icnt[row[u]] + lr[u]] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int k = tid + u * SB;
+            if (k < cn) out[c0 + k] = stage[k];
+        }
+        for (int k = sb; k < se; ++k) icnt[k] = 0;
+        __syncthreads();
+    }
+    // exclusive scan of the row totals: the rows' places in the final arrays
+    int s = 0;
+    for (int k = sb; k < se; ++k) s += tot[k];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < SB; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int* ro = row_off + (int64_t)f * ro_stride;
+    int run = part[tid] - s;
+    for (int k = sb; k < se; ++k) { ro[k] = run; run += tot[k]; }
+    if (tid == SB - 1) ro[nrow] = part[SB - 1];
+}
+
 // ---- the same with every frame split over P blocks (big frames in small batches): three launches ----
 // (a) block (p, f): rows histogram of its share of the frame -> cntb[f][p][row]
 template <typename T>
@@ -566,13 +684,24 @@ __device__ __forceinline__ float wol_pack_cell_tag(int cx, int sub, int rank) {
     return __uint_as_float((unsigned)cx | ((unsigned)sub << 8) | ((unsigned)rank << 10));
 }
 
+#define WOL_SEG_MAXCHUNK 128  // chunks of a frame the segment form of the first level may write (a power of two)
+
+// where the rows' waters lie when the first level wrote segments (k_sort_rows_seg): chunk c of the frame holds the
+// waters [tab[row][c], tab[row + 1][c]) of every row, chunks are `chunk_waters` apart; tab == null: rows are contiguous
+struct RowPieces {
+    const unsigned short* tab;
+    int tab_rows, nchunk_cap, chunk_waters;
+};
+
 template <int SLOTS>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
               const double4* __restrict__ tmp, int n, int* __restrict__ cell_start,
-              double4* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap) {
+              double4* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap, RowPieces rp) {
     extern __shared__ int lds_row_bins[];   // per wave: cnt[nb_cap] (per fine bin: population, then first slot in the row) and
                                             // cur[nb_cap] (long rows: running cursors); nb_cap >= nx * WOL_XSUB of every frame
+    __shared__ int cpre_all[(WOL_BLOCK / 64) * (WOL_SEG_MAXCHUNK + 1)];   // segment form: waters of the row in earlier chunks
+    __shared__ int csrc_all[(WOL_BLOCK / 64) * WOL_SEG_MAXCHUNK];         // ... and where water i of the row lies, minus i
     constexpr int WOL_L2_CAP = 64 * SLOTS;
     __shared__ double4 st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];   // the row in bin order, written out linearly:
     __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
@@ -587,6 +716,10 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     float4* st32 = st32_all + wave * WOL_L2_CAP;
     const int* ro = row_off + (int64_t)f * ro_stride;
     const double4* __restrict__ in = tmp + (int64_t)f * n;
+    int* cpre = cpre_all + wave * (WOL_SEG_MAXCHUNK + 1);
+    int* csrc = csrc_all + wave * WOL_SEG_MAXCHUNK;
+    const unsigned short* __restrict__ tb = rp.tab ? rp.tab + (int64_t)f * rp.tab_rows * rp.nchunk_cap : nullptr;
+    const int nchunk = rp.tab ? (n + rp.chunk_waters - 1) / rp.chunk_waters : 0;
     double4* __restrict__ so = sorted + (int64_t)f * n;
     float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
     const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
@@ -597,6 +730,35 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     for (int cy = wave; cy < ny; cy += WOL_BLOCK / 64) {  // one wave per row, no block-level barriers
         const int row = cz * ny + cy;
         const int b = ro[row], e = ro[row + 1];
+        if (tb) {   // the row's pieces: a lane per chunk, 64 chunks at a time
+            int run = 0;
+            for (int c0 = 0; c0 < nchunk; c0 += 64) {
+                const int c = c0 + lane;
+                const int t0 = c < nchunk ? (int)tb[(int64_t)row * rp.nchunk_cap + c] : 0;
+                const int len = c < nchunk ? (int)tb[(int64_t)(row + 1) * rp.nchunk_cap + c] - t0 : 0;
+                int inc = len;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int t = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += t;
+                }
+                if (c < nchunk) {
+                    cpre[c] = run + inc - len;
+                    csrc[c] = c * rp.chunk_waters + t0 - (run + inc - len);
+                }
+                run += __shfl(inc, 63, 64);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // water i of the row (0 <= i < e - b) in the first level's output
+        auto src_of = [&](int i) -> int {
+            if (!tb) return b + i;
+            int c = 0;
+#pragma unroll
+            for (int step = WOL_SEG_MAXCHUNK / 2; step >= 1; step >>= 1)
+                if (c + step < nchunk && cpre[c + step] <= i) c += step;
+            return csrc[c] + i;
+        };
         int* __restrict__ cs = cell_start + g.cell_base + (int64_t)row * nx;
         unsigned* __restrict__ c4 = cnt4 ? cnt4 + g.cell_base + (int64_t)row * nx : nullptr;
         for (int c = lane; c < nb; c += 64) cnt[c] = 0;
@@ -608,7 +770,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         if (fits) {
             // ---- the usual row: read once (the waters stay in registers), rank = returning LDS atomic ----
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) v[u] = in[min(b + lane + 64 * u, e - 1)];   // all in flight together (e > b here)
+            for (int u = 0; u < SLOTS; ++u) v[u] = in[src_of(min(lane + 64 * u, e - b - 1))];   // all in flight together (e > b here)
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) {
                 const int i = b + lane + 64 * u;
@@ -628,8 +790,8 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             }
         } else {
             // ---- long rows: count first ----
-            for (int i = b + lane; i < e; i += 64) {
-                const double4 p = in[i];
+            for (int i = lane; i < e - b; i += 64) {
+                const double4 p = in[src_of(i)];
                 double ux = p.x * g.box.ib[0]; ux -= floor(ux);
                 int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);
                 const float wx = (float)((ux * (double)nx - (double)cx) * sx);
@@ -692,8 +854,8 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             continue;
         }
         // ---- long rows: scatter straight into the final arrays ----
-        for (int i = b + lane; i < e; i += 64) {
-            const double4 p = in[i];
+        for (int i = lane; i < e - b; i += 64) {
+            const double4 p = in[src_of(i)];
             double ux = p.x * g.box.ib[0]; ux -= floor(ux);
             double uy = p.y * g.box.ib[1]; uy -= floor(uy);
             double uz = p.z * g.box.ib[2]; uz -= floor(uz);
