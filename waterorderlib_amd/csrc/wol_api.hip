@@ -1008,8 +1008,10 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
             const double per_frame = (double)n * 64.0 + 2.0 * frame_bytes;
             Fb = (int)std::fmin((double)Fb, std::fmax(1.0, 6.0e9 / per_frame));
         } else {
+            // device-resident frames: up to 125 M waters per batch (about 30 GB of intermediate arrays in three sets, of
+            // 288 GB) -- a 32-frame block of a million-water box is one batch, not 24 + 8
             const double per_frame = (double)n * 64.0;
-            Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 2.0e9 / per_frame));
+            Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 8.0e9 / per_frame));
         }
         if (Fb >= 8 && Fb < T_frames) Fb = (Fb / 8) * 8;
     }
