@@ -593,9 +593,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             cnt4 = S.cnt4.as<unsigned>();
         }
         if (in_row_stage) WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
-        RowPieces pieces{nullptr, 0, 0, 0};
+        RowPieces pieces{nullptr, 0, 0, 0, 0};
         auto launch_in_row = [&](int ro_stride) {
-            const size_t lds = sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64);
+            const size_t lds = sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64) +
+                               (pieces.tab ? sizeof(unsigned short) * (size_t)pieces.nchunk_cap * pieces.ny_cap + 8 : 0);
             if ((int64_t)n > 100 * (int64_t)std::max(nrow_all, 1))   // long rows (big boxes): four waters per lane
                 hipLaunchKernelGGL(k_sort_in_row<4>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
                                    c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
@@ -655,7 +656,9 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                 // single pass: chunks written as they lie in LDS plus a table of the rows' starts inside every chunk
                 const int chunk_waters = WOL_L1_CHUNK * WOL_SORT_BLOCK, nchunk = (n + chunk_waters - 1) / chunk_waters;
                 WOL_TRY(c->seg_tab.ensure(sizeof(unsigned short) * (size_t)F * (size_t)(nrow_max + 1) * nchunk));
-                pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters};
+                int ny_all = 1;
+                for (int f = 0; f < F; ++f) ny_all = std::max(ny_all, gh[f].nc[1]);
+                pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all + 1};
                 hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
                                    c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);

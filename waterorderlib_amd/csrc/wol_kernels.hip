@@ -478,7 +478,7 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
 // First level, single-pass form ("segments"): one block per frame.  The frame is cut into chunks of CH * SB waters; a
 // chunk is ordered by (z, y) cell row inside LDS (returning atomic = rank inside the row, a scan over the rows) and
 // written out AS IT LIES THERE -- one contiguous 32-byte-record stream per block, no read of the frame beforehand to size
-// row buckets -- together with the start of every row inside the chunk (tab[row][chunk], 16 bit).  The second level's
+// row buckets -- together with the start of every row inside the chunk (tab[chunk][row], 16 bit).  The second level's
 // wave then collects its row from the frame's chunks (~3 waters of the row in each).  The row totals, summed as the
 // chunks go by, give the rows' places in the final arrays (row_off), as before.
 // ---------------------------------------------------------------------------------------------
@@ -552,11 +552,11 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
         for (int k = sb; k < se; ++k) {
             const int v = icnt[k];
             icnt[k] = st;
-            tb[(int64_t)k * nchunk_cap + chunk] = (unsigned short)st;
+            tb[(int64_t)chunk * tab_rows + k] = (unsigned short)st;     // chunk-major: the owners' stores are one 2-KB run
             tot[k] += v;
             st += v;
         }
-        if (tid == SB - 1) tb[(int64_t)nrow * nchunk_cap + chunk] = (unsigned short)cn;   // (row nrow: the end of the last row)
+        if (tid == SB - 1) tb[(int64_t)chunk * tab_rows + nrow] = (unsigned short)cn;   // (row nrow: the end of the last row)
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CH; ++u)
@@ -687,10 +687,11 @@ __device__ __forceinline__ float wol_pack_cell_tag(int cx, int sub, int rank) {
 #define WOL_SEG_MAXCHUNK 128  // chunks of a frame the segment form of the first level may write (a power of two)
 
 // where the rows' waters lie when the first level wrote segments (k_sort_rows_seg): chunk c of the frame holds the
-// waters [tab[row][c], tab[row + 1][c]) of every row, chunks are `chunk_waters` apart; tab == null: rows are contiguous
+// waters [tab[c][row], tab[c][row + 1]) of every row, chunks are `chunk_waters` apart; tab == null: rows are contiguous
 struct RowPieces {
     const unsigned short* tab;
     int tab_rows, nchunk_cap, chunk_waters;
+    int ny_cap;   // rows of a cell layer the block's LDS copy of the table has room for (+ 1)
 };
 
 template <int SLOTS>
@@ -720,6 +721,17 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     int* csrc = csrc_all + wave * WOL_SEG_MAXCHUNK;
     const unsigned short* __restrict__ tb = rp.tab ? rp.tab + (int64_t)f * rp.tab_rows * rp.nchunk_cap : nullptr;
     const int nchunk = rp.tab ? (n + rp.chunk_waters - 1) / rp.chunk_waters : 0;
+    // the block's rows are the ny rows of cell layer cz: their table entries (and the next row's) are ny + 1 consecutive
+    // 16-bit values per chunk -- fetched once, chunk by chunk, into LDS behind the waves' bin counters
+    unsigned short* tabl = reinterpret_cast<unsigned short*>(lds_row_bins + (WOL_BLOCK / 64) * 2 * nb_cap);
+    if (tb) {
+        const int w = ny + 1;
+        for (int idx = threadIdx.x; idx < nchunk * w; idx += WOL_BLOCK) {
+            const int c = idx / w, j = idx - c * w;
+            tabl[idx] = tb[(int64_t)c * rp.tab_rows + cz * ny + j];
+        }
+        __syncthreads();
+    }
     double4* __restrict__ so = sorted + (int64_t)f * n;
     float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
     const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
@@ -734,8 +746,8 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             int run = 0;
             for (int c0 = 0; c0 < nchunk; c0 += 64) {
                 const int c = c0 + lane;
-                const int t0 = c < nchunk ? (int)tb[(int64_t)row * rp.nchunk_cap + c] : 0;
-                const int len = c < nchunk ? (int)tb[(int64_t)(row + 1) * rp.nchunk_cap + c] - t0 : 0;
+                const int t0 = c < nchunk ? (int)tabl[c * (ny + 1) + cy] : 0;
+                const int len = c < nchunk ? (int)tabl[c * (ny + 1) + cy + 1] - t0 : 0;
                 int inc = len;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
