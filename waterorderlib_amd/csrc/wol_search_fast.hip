@@ -535,6 +535,130 @@ __device__ __forceinline__ double wol_guaranteed_radius(const double c[3], const
 }
 
 // ---------------------------------------------------------------------------------------------
+// The trajectory mode's work on one water whose four proposed neighbours are at hand (fp64 coordinates): certify them,
+// form q from their minimum-image vectors in proposal order -- no ranking, no second re-image, shared norms -- bin q and
+// the four distances, add to the frame sums.  Shared by k_finish_fast<true> (neighbours gathered from global memory) and
+// k_finish_tiles (from the tile's LDS copy): the arithmetic is the same statement for statement.  Returns true when the
+// water has to take the exact path instead (nothing has been written for it then).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wol_lean_water(const FastArgs& a, const FrameGrid& g, int f, const double c[3],
+                                               const double nbx[4], const double nby[4], const double nbz[4],
+                                               int kd3, int eps_u, double dinv, int* lds_qh, int* lds_dh, int orig,
+                                               long long* acc_h, long long* acc_l, long long* acc_h2, long long* acc_l2) {
+    bool slow = false;
+    // The minimum-image vectors d themselves stand in for the reference's (apos + d) - apos (wp:372-373) and
+    // for tetraCosAng's second re-image: they differ by rounding of order ulp(apos), 1e-15 relative, which q
+    // tolerates (|dq| < 1e-14) and the distance bins do not notice except on a bin edge -- there the
+    // reference's chain is evaluated.  One rsqrt per neighbour gives both its norm and its distance.
+    // Per neighbour only its unit vector and its distance bin stay live (register pressure decides how many
+    // waves cover the gathers' latency).
+    double ux[4], uy[4], uz[4];
+    int dbin[4];
+    double dmax = 0.0;
+    bool all_in = true;
+    // |d - ((c + d) - c)| per component: two roundings at the magnitude of the coordinates (which may be
+    // unwrapped, i.e. far larger than the box); the bin-edge guards below widen with it
+    const double cguard = 1e-14 * (fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2]))) + a.high);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // waterlib.f90:733-735 with rint for anint: they differ only on exact half-integers, i.e. a neighbour
+        // at exactly half a box length, which the emax test below sends to the exact path anyway
+        const double ex = nbx[k] - c[0], ey = nby[k] - c[1], ez = nbz[k] - c[2];
+        const double dx = ex - g.box.L[0] * rint(ex * g.box.ib[0]);
+        const double dy = ey - g.box.L[1] * rint(ey * g.box.ib[1]);
+        const double dz = ez - g.box.L[2] * rint(ez * g.box.ib[2]);
+        const double d2 = wol_sumsq(dx, dy, dz);
+        // q from d instead of (c + d) - c is off by ~ 4 ulp(c) / d: where that could pass 4e-13 (coordinates
+        // thousands of box lengths from the origin, or a neighbour a few thousandths of an Angstrom away: d below
+        // a thousandth of the coordinates' magnitude) the reference's chain is evaluated, on the exact path
+        const double dlow = cguard * 1e11;
+        all_in = all_in && (d2 > dlow * dlow) && (d2 <= a.highsq);
+        const double rn = rsqrt(d2);
+        const double dist = d2 * rn;
+        dmax = fmax(dmax, dist);
+        ux[k] = dx * rn; uy[k] = dy * rn; uz[k] = dz * rn;
+        // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal; when the product sits
+        // on an integer, the reference's distance and the true division decide
+        const double tq = dist * dinv;
+        double cb = ceil(tq);
+        if (fabs(tq - rint(tq)) < 1e-9 * tq + cguard * dinv) {
+            const double vx = (c[0] + dx) - c[0], vy = (c[1] + dy) - c[1], vz = (c[2] + dz) - c[2];
+            cb = ceil(sqrt(wol_sumsq(vx, vy, vz)) / a.out.dbinwidth);
+        }
+        dbin[k] = (cb >= 1.0 && cb <= (double)a.out.dbins) ? (int)cb - 1 : -1;
+    }
+    // no component of a neighbour vector reaches 0.49 box lengths if the longest vector stays below 0.49 of
+    // the shortest box edge (sufficient; tiny boxes may take the exact path a little more often)
+    const double emax = dmax * fmax(g.box.ib[0], fmax(g.box.ib[1], g.box.ib[2]));
+    // every neighbour inside the smallest cell width is inside the guaranteed radius: the walls only matter beyond
+    const double cwmin = fmin(g.cw[0], fmin(g.cw[1], g.cw[2]));
+    const double rg = (dmax > cwmin - 1e-4) ? wol_guaranteed_radius(c, g, a.rows) : cwmin;
+    const double d3s = (dmax * dmax) * g.S;
+    // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity
+#ifdef WOL_EXP_FINISH_COALESCED
+    if (!(dmax > -1.0) || d3s == 12345.678) {
+#else
+    if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)eps_u || !(emax < 0.49)) {
+#endif
+        slow = true;
+    } else {
+        // the six terms are summed in ascending order of their values: the result must not depend
+        // on the order in which the proposal lists the neighbours (which can follow the arrival
+        // order of waters inside a cell when two fp32 keys tie)
+        double tm[6];
+        {
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 4; ++j) {
+                    const double dot = (ux[i] * ux[j] + uy[i] * uy[j]) + uz[i] * uz[j];
+                    const double cs_ = fmin(1.0, fmax(-1.0, dot)) + (1.0 / 3.0);
+                    tm[m++] = cs_ * cs_;
+                }
+        }
+#define WOL_CE(i, j) { const double lo_ = fmin(tm[i], tm[j]), hi_ = fmax(tm[i], tm[j]); tm[i] = lo_; tm[j] = hi_; }
+        WOL_CE(0, 5) WOL_CE(1, 3) WOL_CE(2, 4)   // 12-comparator sorting network for 6 keys
+        WOL_CE(1, 2) WOL_CE(3, 4)
+        WOL_CE(0, 3) WOL_CE(2, 5)
+        WOL_CE(0, 1) WOL_CE(2, 3) WOL_CE(4, 5)
+        WOL_CE(1, 2) WOL_CE(3, 4)
+#undef WOL_CE
+        double ssum = -0.0;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) ssum += tm[m];
+        const double q = 1.0 - (3.0 / 8.0) * ssum;
+        // This q is within 2e-14 of the reference's acos -> degrees -> cos chain (wp:376-388), which is what
+        // np.histogram bins (opl:1493).  Where that could matter -- q within 1e-8 of a bin width from a bin edge
+        // (0 and 1 included) -- the water goes to the exact kernel, which evaluates the reference's chain in
+        // exact rank order: the integer histogram is the reference's by construction.
+        const double tq_ = q * (double)a.out.qbins;
+        if (lds_qh && fabs(tq_ - rint(tq_)) < 1e-8 + cguard * (double)a.out.qbins && tq_ > -0.5 &&
+            tq_ < (double)a.out.qbins + 0.5) {
+            slow = true;
+        } else {
+            if (a.out.q || a.out.q32) {
+                const int64_t orow = (int64_t)f * a.n + orig;
+                if (a.out.q) a.out.q[orow] = q;
+                if (a.out.q32) a.out.q32[orow] = (float)q;
+            }
+            wol_fix_split_fast(q, acc_h, acc_l);
+            wol_fix_split_fast(q * q, acc_h2, acc_l2);
+            if (lds_qh) {
+                const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
+                if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
+            }
+            if (lds_dh) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (dbin[k] >= 0) atomicAdd(&lds_dh[dbin[k]], 1);
+            }
+        }
+    }
+    return slow;
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernel 2: certification + epilogue, one lane per water in sorted order.  Re-evaluates the four
 // proposed neighbours from the fp64 coordinates with the reference's arithmetic, accepts when the
 // 4th distance is inside the radius the 27-cell stencil guarantees (and agrees with the fp32 key),
@@ -594,115 +718,10 @@ k_finish_fast(FastArgs a) {
 #else
             const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
 #endif
-            // The minimum-image vectors d themselves stand in for the reference's (apos + d) - apos (wp:372-373) and
-            // for tetraCosAng's second re-image: they differ by rounding of order ulp(apos), 1e-15 relative, which q
-            // tolerates (|dq| < 1e-14) and the distance bins do not notice except on a bin edge -- there the
-            // reference's chain is evaluated.  One rsqrt per neighbour gives both its norm and its distance.
-            // Per neighbour only its unit vector and its distance bin stay live (register pressure decides how many
-            // waves cover the gathers' latency).
-            double ux[4], uy[4], uz[4];
-            int dbin[4];
-            double dmax = 0.0;
-            bool all_in = true;
-            // |d - ((c + d) - c)| per component: two roundings at the magnitude of the coordinates (which may be
-            // unwrapped, i.e. far larger than the box); the bin-edge guards below widen with it
-            const double cguard = 1e-14 * (fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2]))) + a.high);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // waterlib.f90:733-735 with rint for anint: they differ only on exact half-integers, i.e. a neighbour
-                // at exactly half a box length, which the emax test below sends to the exact path anyway
-                const double ex = nb[k].x - c[0], ey = nb[k].y - c[1], ez = nb[k].z - c[2];
-                const double dx = ex - g.box.L[0] * rint(ex * g.box.ib[0]);
-                const double dy = ey - g.box.L[1] * rint(ey * g.box.ib[1]);
-                const double dz = ez - g.box.L[2] * rint(ez * g.box.ib[2]);
-                const double d2 = wol_sumsq(dx, dy, dz);
-                // q from d instead of (c + d) - c is off by ~ 4 ulp(c) / d: where that could pass 4e-13 (coordinates
-                // thousands of box lengths from the origin, or a neighbour a few thousandths of an Angstrom away: d below
-                // a thousandth of the coordinates' magnitude) the reference's chain is evaluated, on the exact path
-                const double dlow = cguard * 1e11;
-                all_in = all_in && (d2 > dlow * dlow) && (d2 <= a.highsq);
-                const double rn = rsqrt(d2);
-                const double dist = d2 * rn;
-                dmax = fmax(dmax, dist);
-                ux[k] = dx * rn; uy[k] = dy * rn; uz[k] = dz * rn;
-                // nbin = ceiling(d/binwidth) (waterlib.f90:219-222): multiply by the reciprocal; when the product sits
-                // on an integer, the reference's distance and the true division decide
-                const double tq = dist * dinv;
-                double cb = ceil(tq);
-                if (fabs(tq - rint(tq)) < 1e-9 * tq + cguard * dinv) {
-                    const double vx = (c[0] + dx) - c[0], vy = (c[1] + dy) - c[1], vz = (c[2] + dz) - c[2];
-                    cb = ceil(sqrt(wol_sumsq(vx, vy, vz)) / a.out.dbinwidth);
-                }
-                dbin[k] = (cb >= 1.0 && cb <= (double)a.out.dbins) ? (int)cb - 1 : -1;
-            }
-            // no component of a neighbour vector reaches 0.49 box lengths if the longest vector stays below 0.49 of
-            // the shortest box edge (sufficient; tiny boxes may take the exact path a little more often)
-            const double emax = dmax * fmax(g.box.ib[0], fmax(g.box.ib[1], g.box.ib[2]));
-            // every neighbour inside the smallest cell width is inside the guaranteed radius: the walls only matter beyond
-            const double cwmin = fmin(g.cw[0], fmin(g.cw[1], g.cw[2]));
-            const double rg = (dmax > cwmin - 1e-4) ? wol_guaranteed_radius(c, g, a.rows) : cwmin;
-            const double d3s = (dmax * dmax) * g.S;
-            // emax < 0.49: tetraCosAng's second re-image (waterlib.f90:881-883) is the identity
-#ifdef WOL_EXP_FINISH_COALESCED
-            if (!(dmax > -1.0) || d3s == 12345.678) {
-#else
-            if (!all_in || !(dmax <= rg) || fabs(d3s - (double)kd3) > (double)eps_u || !(emax < 0.49)) {
-#endif
-                slow = true;
-            } else {
-                // the six terms are summed in ascending order of their values: the result must not depend
-                // on the order in which the proposal lists the neighbours (which can follow the arrival
-                // order of waters inside a cell when two fp32 keys tie)
-                double tm[6];
-                {
-                    int m = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = i + 1; j < 4; ++j) {
-                            const double dot = (ux[i] * ux[j] + uy[i] * uy[j]) + uz[i] * uz[j];
-                            const double cs_ = fmin(1.0, fmax(-1.0, dot)) + (1.0 / 3.0);
-                            tm[m++] = cs_ * cs_;
-                        }
-                }
-#define WOL_CE(i, j) { const double lo_ = fmin(tm[i], tm[j]), hi_ = fmax(tm[i], tm[j]); tm[i] = lo_; tm[j] = hi_; }
-                WOL_CE(0, 5) WOL_CE(1, 3) WOL_CE(2, 4)   // 12-comparator sorting network for 6 keys
-                WOL_CE(1, 2) WOL_CE(3, 4)
-                WOL_CE(0, 3) WOL_CE(2, 5)
-                WOL_CE(0, 1) WOL_CE(2, 3) WOL_CE(4, 5)
-                WOL_CE(1, 2) WOL_CE(3, 4)
-#undef WOL_CE
-                double ssum = -0.0;
-#pragma unroll
-                for (int m = 0; m < 6; ++m) ssum += tm[m];
-                const double q = 1.0 - (3.0 / 8.0) * ssum;
-                // This q is within 2e-14 of the reference's acos -> degrees -> cos chain (wp:376-388), which is what
-                // np.histogram bins (opl:1493).  Where that could matter -- q within 1e-8 of a bin width from a bin edge
-                // (0 and 1 included) -- the water goes to the exact kernel, which evaluates the reference's chain in
-                // exact rank order: the integer histogram is the reference's by construction.
-                const double tq_ = q * (double)a.out.qbins;
-                if (lds_qh && fabs(tq_ - rint(tq_)) < 1e-8 + cguard * (double)a.out.qbins && tq_ > -0.5 &&
-                    tq_ < (double)a.out.qbins + 0.5) {
-                    slow = true;
-                } else {
-                    if (a.out.q || a.out.q32) {
-                        const int64_t orow = (int64_t)f * a.n + (int)__double_as_longlong(mev.w);
-                        if (a.out.q) a.out.q[orow] = q;
-                        if (a.out.q32) a.out.q32[orow] = (float)q;
-                    }
-                    wol_fix_split_fast(q, &acc_h, &acc_l);
-                    wol_fix_split_fast(q * q, &acc_h2, &acc_l2);
-                    if (lds_qh) {
-                        const int bin = wol_np_hist_bin(q, a.out.qbins, 0.0, 1.0);
-                        if (bin >= 0) atomicAdd(&lds_qh[bin], 1);
-                    }
-                    if (lds_dh) {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (dbin[k] >= 0) atomicAdd(&lds_dh[dbin[k]], 1);
-                    }
-                }
-            }
+            const double nbx[4] = {nb[0].x, nb[1].x, nb[2].x, nb[3].x}, nby[4] = {nb[0].y, nb[1].y, nb[2].y, nb[3].y},
+                         nbz[4] = {nb[0].z, nb[1].z, nb[2].z, nb[3].z};
+            slow = wol_lean_water(a, g, f, c, nbx, nby, nbz, kd3, eps_u, dinv, lds_qh, lds_dh, (int)__double_as_longlong(mev.w),
+                                  &acc_h, &acc_l, &acc_h2, &acc_l2);
         } } else if (live && !slow) {
             const int4 pr = pr_all;
             const double4 mev = mev_all;
