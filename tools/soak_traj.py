@@ -21,6 +21,9 @@ for seed in range(first, first + count):
     if seed % 5 == 0: box0[rng.integers(3)] = rng.uniform(13.7, 15.0)
     rho = rng.choice([0.0334, 0.0334, 0.025, 0.045, 0.012])
     n = int(min(max(rho * np.prod(box0), 200), 40000 if big else 12000))
+    if seed >= 10000:                                     # seeds from 10000: many frames of 25-60 k waters (the single-pass
+        T = int(rng.integers(64, 81))                     # first sort level, full batches)
+        n = int(rng.integers(25000, 60000)); box0 = box0 * (n / (rho * np.prod(box0))) ** (1.0 / 3.0)
     npt = seed % 3 != 0
     boxes = box0 * (1.0 + (rng.uniform(-0.04, 0.04, size=(T, 3)) if npt else np.zeros((T, 3))))
     len_wat = int(rng.choice([1, 1, 3, 4]))
