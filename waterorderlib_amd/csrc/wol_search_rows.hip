@@ -45,7 +45,10 @@
 #ifndef WOL_ROWS_ROUNDS
 #define WOL_ROWS_ROUNDS 1      // sweep rounds per wave a tile is sized for (experiments: 2 = tiles twice as tall)
 #endif
-#define WOL_ROWS_TARGET(block) (((block) * 97 * WOL_ROWS_ROUNDS) / 100)
+#ifndef WOL_ROWS_FILL
+#define WOL_ROWS_FILL 97
+#endif
+#define WOL_ROWS_TARGET(block) (((block) * WOL_ROWS_FILL * WOL_ROWS_ROUNDS) / 100)
 #define WOL_ROWS_CSCALE 0.0009765625f   // 2^-10
 #ifndef WOL_ROWS_WPS
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
