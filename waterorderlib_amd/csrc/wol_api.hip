@@ -1044,10 +1044,20 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
     // interleaved frames: measured on MI355X, a strided copy of the 24-byte O rows -- hipMemcpy2DAsync or a gather
     // kernel over mapped host memory -- is no faster than the linear copy of everything, tools/pcie_probe.hip), the
     // kernels pick the O rows out of the staged frames through the atom stride.
-    const int nbatch = (T_frames + Fb - 1) / Fb;
+    // batch b = frames [bstart[b], bstart[b + 1]).  Host frames: what the call costs beyond the copies is the kernels of the
+    // LAST batch (nothing crosses the link under them), so the tail of a several-batch call is cut off as a batch of its own
+    // of at most 32 frames
+    std::vector<int> bstart;
+    for (int f0 = 0; f0 < T_frames; f0 += Fb) bstart.push_back(f0);
+    bstart.push_back(T_frames);
+    if (host && c->frames_per_batch <= 0 && bstart.size() >= 3) {
+        const int last = T_frames - bstart[bstart.size() - 2];
+        if (last > 48) bstart.insert(bstart.end() - 1, T_frames - 32);
+    }
+    const int nbatch = (int)bstart.size() - 1;
     auto batch_elems = [&](int F) { return (size_t)(F - 1) * frame_stride + (size_t)(n - 1) * atom_stride + 3; };
     auto enqueue_copy = [&](int b) -> int {
-        const int f0 = b * Fb, F = std::min(Fb, T_frames - f0), k = b & 1;
+        const int f0 = bstart[b], F = bstart[b + 1] - f0, k = b & 1;
         if (b >= 2) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->consumed_ev[k], 0));   // batch b-2 is done with this set
         HIP_TRY(hipMemcpyAsync(c->host_stage[k].p, frames + (int64_t)f0 * frame_stride, batch_elems(F) * sizeof(T),
                                hipMemcpyHostToDevice, c->copy_stream));
@@ -1069,8 +1079,8 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
     }
 
     for (int b = 0; b < nbatch; ++b) {
-        const int f0 = b * Fb;
-        const int F = std::min(Fb, T_frames - f0);
+        const int f0 = bstart[b];
+        const int F = bstart[b + 1] - f0;
         FramesView<T> fv;
         fv.atom_stride = atom_stride;
         fv.frame_stride = frame_stride;
