@@ -37,6 +37,7 @@ extern "C" {
 #define WOL_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define WOL_ERR_NOMEM (-3)    /* device or host allocation failed */
 #define WOL_ERR_NODEVICE (-4) /* no usable GPU */
+#define WOL_ERR_PEER (-5)     /* frame-sharded calls: another rank failed in its local part (this rank's results are not written) */
 
 #define WOL_MEM_HOST 0
 #define WOL_MEM_DEVICE 1
@@ -73,7 +74,10 @@ int wol_ctx_synchronize(wol_ctx* ctx);
  * memory when a call is made, not merely enqueued earlier on the stream, so the sort of one call may overlap
  * the previous call's kernels; default 0), "time_kernels" (0/1: HIP-event timing of the dominant kernel,
  * read back with wol_ctx_kernel_time), "rows_block" (0 = the proposal kernel's instantiation is picked per batch by lane
- * fill, default; 512 / 768 = force that k_search_rows instantiation: tests and tuning) */
+ * fill, default; 512 / 768 = force that k_search_rows instantiation: tests and tuning), "check_proposals" (diagnostic, 0/1:
+ * the proposal arrays are poisoned before the row-merged proposal kernel and a counting kernel behind it checks that the
+ * kernel wrote a key for every water it was given -- counters "proposals_written", "proposals_expected", "proposals_bad";
+ * switching it on or off restarts the counters) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
@@ -83,7 +87,8 @@ int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int r
  * "slow_waters" = waters the fp32 filter could not certify and the exact search finished;
  * "density_level" = tile-shape level the device picked for frame 0 (0 = box-average density);
  * "rows_block" = threads per block of the k_search_rows instantiation that ran (0: another proposal kernel);
- * "h2d_bytes" = bytes the last host-memory trajectory call sent over the host link */
+ * "h2d_bytes" = bytes the last host-memory trajectory call sent over the host link;
+ * "proposals_written" / "proposals_expected" / "proposals_bad": see option "check_proposals" (accumulated, not per call) */
 int wol_ctx_get_counter(wol_ctx* ctx, const char* key, int64_t* value);
 
 /* ---- level 1: the f2py `waterlib` routines on the path (host pointers) -------------------- */
@@ -234,8 +239,15 @@ int wol_comm_adopt(void* nccl_comm, int rank, int world, wol_comm** out);
 int wol_comm_destroy(wol_comm* comm);
 /* wol_q_traj on this rank's T_local frames (frames / boxes / q_out are the LOCAL block) followed by the exchange step:
  * qhist / dhist receive (accumulate, as wol_q_traj) the job-wide counts, mean / var [T_total] the series of all frames
- * in trajectory order, on every rank.  Collective: every rank of the communicator must call it.  With WOL_MEM_DEVICE
- * everything is enqueued on the context's stream. */
+ * in trajectory order, on every rank.  Collective: every rank of the communicator must call it.
+ * Errors are agreed on: a rank whose local part fails (bad arguments, a failed copy or launch, out of memory in the pipeline)
+ * still takes part in the exchange with zeros and a raised status word that rides on the histogram all-reduce, so no
+ * rank is left waiting inside RCCL; that rank returns its own error, every other rank WOL_ERR_PEER, and nobody's output
+ * arrays are written.  Only a rank that cannot reach the exchange at all (no device, NULL communicator, no memory for
+ * the KB-sized exchange buffer) returns early -- abort the communicator then, as for any collective.  The status word is
+ * read on the host, so the call synchronises the context's stream once in either memory mode.
+ * The world > 1 path has not yet run on hardware (no multi-GPU box was available to this build): covered by a
+ * one-rank RCCL test and a two-rank test that is skipped on one-GPU boxes. */
 int wol_q_traj_sharded(wol_ctx* ctx, wol_comm* comm, const double* frames, int64_t atom_stride, int64_t frame_stride,
                        int T_local, int T_total, int n, const double* boxes, double lowcut, double highcut,
                        double* mean, double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,

@@ -4,34 +4,18 @@ waters.  The 4th / 5th neighbour tie sends (nearly) every water to the exact ker
 the reference's (the oracle's).      python tools/soak_lattice.py [first_seed] [count]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from waterorderlib_amd import _lib, water_properties as wp
 import wol_oracle
+import soak_gen
 wol_oracle.set_threads(16)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-BASES = {
-    "sc": np.array([[0, 0, 0]], float),
-    "fcc": np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0]], float),
-    "diamond": np.array([[0, 0, 0], [0, .5, .5], [.5, 0, .5], [.5, .5, 0],
-                         [.25, .25, .25], [.25, .75, .75], [.75, .25, .75], [.75, .75, .25]], float),
-}
 bad = 0
 for seed in range(first, first + count):
-    rng = np.random.default_rng(5000 + seed)
-    kind = ["sc", "fcc", "diamond"][seed % 3]
-    a = {"sc": 3.1, "fcc": 4.4, "diamond": 6.35}[kind] * rng.choice([1.0, 1.0, 0.97, 1.1])
-    reps = rng.integers(4, 9, size=3) if kind != "sc" else rng.integers(6, 16, size=3)
-    if seed >= 100: reps = reps * 2                           # seeds from 100: eight times the waters
-    g = np.stack(np.meshgrid(*[np.arange(r) for r in reps], indexing="ij"), axis=-1).reshape(-1, 1, 3)
-    pos = ((g + BASES[kind][None]) * a).reshape(-1, 3)
-    box = reps * a
-    jitter = [0.0, 0.0, 1e-13, 1e-9, 1e-4][seed % 5]
-    if jitter: pos = pos + rng.normal(0.0, jitter, size=pos.shape)
-    pos = pos[rng.permutation(len(pos))]
-    if seed % 4 == 1: pos = pos + rng.integers(-2, 3, size=pos.shape) * box
-    if seed % 4 == 2: pos = pos + rng.random(3) * box           # off the cell walls
+    pos, box, kind, jitter = soak_gen.lattice_case(seed)
+    a = 0.0
     n = len(pos)
     q_o, idx_o, dist_o, ang_o = wol_oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
     for rows in (1, 0):

@@ -3,26 +3,18 @@ kernels and whichever instantiation the host picks; every water's indices, dista
     python tools/soak_random.py [first_seed] [count]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from waterorderlib_amd import _lib, water_properties as wp
 import wol_oracle
+import soak_gen
 wol_oracle.set_threads(16)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 for seed in range(first, first + count):
-    rng = np.random.default_rng(seed)
-    box = rng.uniform(13.6, 120.0, size=3)
-    if seed % 4 == 0: box[rng.integers(3)] = rng.uniform(13.6, 15.0)
-    rho = rng.choice([0.0334, 0.0334, 0.02, 0.05, 0.01, 0.07])
-    n = int(min(max(rho * np.prod(box), 300), 20000))
-    pos = rng.random((n, 3)) * box
-    if seed % 2 == 1:
-        k = n // 3
-        centres = rng.random((5, 3)) * box
-        pos[:k] = centres[rng.integers(5, size=k)] + rng.normal(0.0, 2.5, size=(k, 3))
-    pos += rng.integers(-1, 2, size=pos.shape) * box
+    pos, box = soak_gen.random_case(seed)
+    n = len(pos); rho = n / np.prod(box)
     q_o, idx_o, dist_o, ang_o = wol_oracle.getOrderParamq(pos, pos, box, full=True, cells=True)
     for rows in (1, 0):
         c = _lib.Context(0); c.set_option("path", 3); c.set_option("search_rows", rows)

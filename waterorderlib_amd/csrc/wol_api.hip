@@ -113,6 +113,7 @@ struct wol_ctx {
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
     size_t sort_rows_lds_set = 0;
+    size_t in_row_static_lds[2] = {0, 0}, in_row_dyn_limit[2] = {0, 0};   // k_sort_in_row<2> / <4>: static LDS, dynamic LDS allowed so far
     int last_rows_block = 0;
     int force_rows_block = 0;  // 0 = per batch by lane fill; 512 / 768 = that k_search_rows instantiation (tests, tuning)
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
@@ -121,6 +122,9 @@ struct wol_ctx {
                              // more (smaller frames sort faster through row buckets: their second read comes out of L2), 2 = whenever it applies, 0 = never
     int stages = 2;          // pipe depth of the trajectory path: 2 = sort | proposal + certification, 3 = sort | proposal | certification
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
+    bool check_props = false;       // diagnostic: poison the proposal arrays, count what the proposal kernel writes (k_check_props)
+    DevBuf prop_counters;           // {keys written, proposals naming a slot outside the frame} since the option was switched on
+    int64_t prop_expected = 0;      // waters the row kernel was given since then
     SortSet* last_set = nullptr;
     DevBuf seg_tab;   // segment form of the first sort level: start of every row inside every chunk (16 bit)
     DevBuf cellid, rank, qbuf, in_stage, out_stage, hist_stage, small, stat, layer_off, sort_tmp, slow_list, slow_count, stamps, scan_tot;
@@ -508,10 +512,9 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             ss = c->sort_stream;
             if (c->stages >= 3) qs = c->search_stream;
             if (!c->inputs_resident) {
-                // the frames may be the product of work the caller enqueued earlier on its stream: the first batch of a
-                // call marks that point, the later batches of the call wait for the same mark (not for each other)
-                if (allow_pipe == 1) HIP_TRY(hipEventRecord(c->in_ev, c->stream));
-                HIP_TRY(hipStreamWaitEvent(ss, c->in_ev, 0));
+                // the frames may be the product of work the caller enqueued earlier on its stream: the call marks that
+                // point before its first batch, every piped batch of the call waits for that mark (not for each other)
+                HIP_TRY(hipStreamWaitEvent(ss, c->in_ev, 0));   // (recorded once per call, before its first batch: q_traj_impl)
             }
             if (S.used) HIP_TRY(hipStreamWaitEvent(ss, S.free_ev, 0));  // last readers of this set are done
         }
@@ -587,6 +590,8 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             nrow_all = std::max(nrow_all, gh[f].nc[1] * gh[f].nc[2]);
             nb_cap = std::max(nb_cap, std::min(gh[f].nc[0], WOL_L2_MAXNX) * WOL_XSUB);
         }
+        int ny_all_frames = 1;
+        for (int f = 0; f < F; ++f) ny_all_frames = std::max(ny_all_frames, gh[f].nc[1]);
         unsigned* cnt4 = nullptr;
         if (use_fast && rows_kernel) {
             WOL_TRY(S.cnt4.ensure(sizeof(unsigned) * (size_t)cell_total));
@@ -594,10 +599,36 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         }
         if (in_row_stage) WOL_TRY(c->sort_tmp.ensure(sizeof(double4) * (size_t)F * n));
         RowPieces pieces{nullptr, 0, 0, 0, 0};
+        const bool in_row_long = (int64_t)n > 100 * (int64_t)std::max(nrow_all, 1);   // long rows (big boxes): four waters per lane
+        // dynamic LDS of the second level: the waves' bin counters and, in the segment form, the layer's copy of the row table
+        auto in_row_lds = [&](int nchunk, int ny_cap) -> size_t {
+            return sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64) + (nchunk ? sizeof(unsigned short) * (size_t)nchunk * ny_cap + 8 : 0);
+        };
+        // does it fit next to the kernel's static arrays?  (raises the kernel's dynamic-LDS limit when it has to: a long thin
+        // box has hundreds of rows per layer and a hundred chunks)
+        auto in_row_fits = [&](size_t dyn) -> bool {
+            const void* fn = in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4>) : reinterpret_cast<const void*>(&k_sort_in_row<2>);
+            size_t& stat = c->in_row_static_lds[in_row_long ? 1 : 0];
+            size_t& limit = c->in_row_dyn_limit[in_row_long ? 1 : 0];
+            if (!stat) {
+                hipFuncAttributes fa_;
+                if (hipFuncGetAttributes(&fa_, fn) != hipSuccess) return false;
+                stat = fa_.sharedSizeBytes ? fa_.sharedSizeBytes : 1;
+                limit = 64 * 1024 > stat ? 64 * 1024 - stat : 0;
+            }
+            if (stat + dyn > 160 * 1024) return false;
+            if (dyn > limit) {
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - stat)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    return false;
+                }
+                limit = 160 * 1024 - stat;
+            }
+            return true;
+        };
         auto launch_in_row = [&](int ro_stride) {
-            const size_t lds = sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64) +
-                               (pieces.tab ? sizeof(unsigned short) * (size_t)pieces.nchunk_cap * pieces.ny_cap + 8 : 0);
-            if ((int64_t)n > 100 * (int64_t)std::max(nrow_all, 1))   // long rows (big boxes): four waters per lane
+            const size_t lds = in_row_lds(pieces.tab ? pieces.nchunk_cap : 0, pieces.ny_cap);
+            if (in_row_long)
                 hipLaunchKernelGGL(k_sort_in_row<4>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
                                    c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
                                    S.sorted.as<double4>(), s32, cnt4, nb_cap, pieces);
@@ -652,13 +683,12 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                                    wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_PIPE, WOL_L1_BLOCK_PIPE), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
             } else if (P == 1 && c->seg_sort && (n + WOL_L1_CHUNK * WOL_SORT_BLOCK - 1) / (WOL_L1_CHUNK * WOL_SORT_BLOCK) <= WOL_SEG_MAXCHUNK &&
-                       (c->seg_sort >= 2 || n >= 8 * WOL_L1_CHUNK * WOL_SORT_BLOCK)) {
+                       (c->seg_sort >= 2 || n >= 8 * WOL_L1_CHUNK * WOL_SORT_BLOCK) &&
+                       in_row_fits(in_row_lds((n + WOL_L1_CHUNK * WOL_SORT_BLOCK - 1) / (WOL_L1_CHUNK * WOL_SORT_BLOCK), ny_all_frames + 1))) {
                 // single pass: chunks written as they lie in LDS plus a table of the rows' starts inside every chunk
                 const int chunk_waters = WOL_L1_CHUNK * WOL_SORT_BLOCK, nchunk = (n + chunk_waters - 1) / chunk_waters;
                 WOL_TRY(c->seg_tab.ensure(sizeof(unsigned short) * (size_t)F * (size_t)(nrow_max + 1) * nchunk));
-                int ny_all = 1;
-                for (int f = 0; f < F; ++f) ny_all = std::max(ny_all, gh[f].nc[1]);
-                pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all + 1};
+                pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all_frames + 1};
                 hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
                                    c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);
@@ -748,6 +778,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             // waters per cell) is then finished by the exact kernel instead of being certified from whatever the buffer
             // held.  (The row kernel writes a key for every water of every tile it is given, overflowing tiles included.)
             if (!rows_kernel) HIP_TRY(hipMemsetAsync(S.prop_key.p, 0xFF, sizeof(int) * (size_t)F * n, qs));
+            else if (c->check_props) {
+                HIP_TRY(hipMemsetAsync(S.prop_key.p, WOL_PROP_POISON & 0xFF, sizeof(int) * (size_t)F * n, qs));
+                HIP_TRY(hipMemsetAsync(S.prop.p, 0x7F, sizeof(int4) * (size_t)F * n, qs));
+            }
             if (!level_early) {
                 WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
                 hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, (const int*)nullptr, 0, S.level.as<int>());
@@ -784,6 +818,11 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             else if (rows_block == WOL_ROWS_BLOCK_B) hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_B), 0, qs, fa);
             else hipLaunchKernelGGL((k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>), dim3(fgrid), dim3(WOL_ROWS_BLOCK_A), 0, qs, fa);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev, qs));
+            if (rows_kernel && c->check_props) {
+                hipLaunchKernelGGL(k_check_props, dim3(1024), dim3(256), 0, qs, S.prop_key.as<int>(), S.prop.as<int4>(), (int64_t)F * n, n,
+                                   c->prop_counters.as<unsigned long long>());
+                c->prop_expected += (int64_t)n_cell_frames * n;
+            }
             if (pipe && qs != c->stream) {   // the certification stage follows on the caller-visible stream
                 HIP_TRY(hipEventRecord(S.searched_ev, qs));
                 HIP_TRY(hipStreamWaitEvent(c->stream, S.searched_ev, 0));
@@ -1078,6 +1117,12 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         WOL_TRY(enqueue_copy(0));
     }
 
+    if (c->overlap && !host && !c->inputs_resident) {
+        // overlapped batches sort on a side stream: mark, once per call and whether or not the first batch is piped, the
+        // point of the caller's stream behind which the frames are complete
+        if (!c->in_ev) HIP_TRY(hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->in_ev, c->stream));
+    }
     for (int b = 0; b < nbatch; ++b) {
         const int f0 = bstart[b];
         const int F = bstart[b + 1] - f0;
@@ -1210,7 +1255,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     if (c->search_stream) { (void)hipStreamSynchronize(c->search_stream); (void)hipStreamDestroy(c->search_stream); }
     if (c->grid_stream) { (void)hipStreamSynchronize(c->grid_stream); (void)hipStreamDestroy(c->grid_stream); }
     for (DevBuf* b : bufs) b->release();
-    c->cvt_in.release(); c->xchg.release(); c->stat_part.release();
+    c->cvt_in.release(); c->xchg.release(); c->stat_part.release(); c->prop_counters.release();
     for (auto& b : c->cvt_out) b.release();
     for (int k = 0; k < 2; ++k) {
         c->host_stage[k].release();
@@ -1263,17 +1308,30 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
             return fail(WOL_ERR_INVALID, "rows_block must be 0, %d or %d", WOL_ROWS_BLOCK_A, WOL_ROWS_BLOCK_B);
         c->force_rows_block = v;
     } else if (k == "sort_parts") {
+        if (!(value >= 0 && value <= 64)) return fail(WOL_ERR_INVALID, "sort_parts must be 0..64");
         c->sort_parts = (int)value;
     } else if (k == "dyn_tiles") {
+        if (value != 0.0 && value != 1.0) return fail(WOL_ERR_INVALID, "dyn_tiles must be 0 or 1");
         c->dyn_tiles = (int)value;
     } else if (k == "seg_sort") {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail(WOL_ERR_INVALID, "seg_sort must be 0, 1 or 2");
         c->seg_sort = (int)value;
     } else if (k == "stages") {
+        if (value != 2.0 && value != 3.0) return fail(WOL_ERR_INVALID, "stages must be 2 or 3");
         c->stages = (int)value;
     } else if (k == "search_margin") {
+        if (!(value >= 0 && value <= 2)) return fail(WOL_ERR_INVALID, "search_margin must be 0..2");
         c->search_margin = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0.0;
+    } else if (k == "check_proposals") {
+        // (re)starts the counters "proposals_written" / "proposals_expected" / "proposals_bad"
+        WOL_TRY(check_ctx(c));
+        WOL_TRY(c->prop_counters.ensure(sizeof(unsigned long long) * 2));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemset(c->prop_counters.p, 0, sizeof(unsigned long long) * 2));
+        c->prop_expected = 0;
+        c->check_props = value != 0.0;
     } else if (k == "lds_sort") {
         c->lds_sort = value != 0.0;
     } else if (k == "time_kernels") {
@@ -1304,6 +1362,18 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
             HIP_TRY(hipMemcpy(&v, c->last_set->work.as<int>() + 16 * 8, sizeof(int), hipMemcpyDeviceToHost));
             *value = v;
         }
+        return WOL_OK;
+    }
+    if (std::string(key) == "proposals_written" || std::string(key) == "proposals_bad" || std::string(key) == "proposals_expected") {
+        // diagnostic counters of option "check_proposals": keys the row-merged proposal kernel wrote / proposals naming a
+        // slot outside their frame / waters it was given, since the option was switched on
+        if (!c->prop_counters.p) return fail(WOL_ERR_INVALID, "counter '%s' needs option check_proposals", key);
+        if (key[10] == 'e') { *value = c->prop_expected; return WOL_OK; }
+        unsigned long long v[2] = {0, 0};
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->search_stream) HIP_TRY(hipStreamSynchronize(c->search_stream));
+        HIP_TRY(hipMemcpy(v, c->prop_counters.p, sizeof v, hipMemcpyDeviceToHost));
+        *value = (int64_t)v[key[10] == 'w' ? 0 : 1];
         return WOL_OK;
     }
     if (std::string(key) == "h2d_bytes") {   // bytes the last host-memory trajectory call sent over the link
@@ -1961,31 +2031,40 @@ template <typename T>
 int q_traj_sharded_impl(wol_ctx* c, wol_comm* comm, const T* frames, int64_t atom_stride, int64_t frame_stride, int T_local,
                         int T_total, int n, const double* boxes, double low, double high, double* mean, double* var,
                         int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, T* q_out, int mem) {
+    // Failures that keep this rank out of the exchange altogether (no device, no communicator, no exchange buffer) return at
+    // once -- the caller must then abort the communicator, as with any collective.  EVERY other failure of this rank (bad
+    // arguments, a failed copy, a failed kernel launch, out of memory in the pipeline) is held back until after the exchange:
+    // the rank contributes zeros plus a status word that rides on the histogram all-reduce, so that all ranks leave the
+    // collectives together and all of them return an error (this rank its own, the others WOL_ERR_PEER).
     WOL_TRY(check_ctx(c));
     if (!comm) return fail(WOL_ERR_INVALID, "q_traj_sharded: communicator must not be NULL");
-    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
-    int t0 = 0, t1 = 0;
-    WOL_TRY(wol_shard_bounds(T_total, comm->rank, comm->world, &t0, &t1));
-    if (T_local != t1 - t0)
-        return fail(WOL_ERR_INVALID, "q_traj_sharded: rank %d of %d owns frames [%d, %d) of %d, got %d frames", comm->rank,
-                    comm->world, t0, t1, T_total, T_local);
-    if (qhist && qbins <= 0) return fail(WOL_ERR_INVALID, "qbins must be > 0");
-    if (dhist && (dbins <= 0 || !(dbinwidth > 0.0))) return fail(WOL_ERR_INVALID, "dbins/dbinwidth must be > 0");
     const bool host = (mem == WOL_MEM_HOST);
     const int W = comm->world;
-    const int per = (T_total + W - 1) / W;            // frames per rank, padded: shards differ by at most one frame
-    const int nh = (qhist ? qbins : 0) + (dhist ? dbins : 0);
-    // exchange buffer (device): hist[nh] uint64 | mine[per][2] doubles | all[W][per][2] doubles
-    const size_t o_mine = sizeof(unsigned long long) * (size_t)std::max(nh, 1);
+    const int Tt = std::max(T_total, 0);
+    const int per = (Tt + W - 1) / W;                 // frames per rank, padded: shards differ by at most one frame
+    const int nq = (qhist && qbins > 0) ? qbins : 0, nd = (dhist && dbins > 0) ? dbins : 0;
+    const int nh = nq + nd;
+    // exchange buffer (device): hist[nh] uint64 | status[1] uint64 | mine[per][2] doubles | all[W][per][2] doubles
+    const size_t o_mine = sizeof(unsigned long long) * (size_t)(nh + 1);
     const size_t o_all = o_mine + sizeof(double) * 2 * (size_t)per;
     WOL_TRY(c->xchg.ensure(o_all + sizeof(double) * 2 * (size_t)per * W));
     char* xb = c->xchg.as<char>();
     unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(xb);
+    unsigned long long* d_status = d_hist + nh;
     double* d_mine = reinterpret_cast<double*>(xb + o_mine);
     double* d_all = reinterpret_cast<double*>(xb + o_all);
     HIP_TRY(hipMemsetAsync(xb, 0, o_all, c->stream));
     // ---- this rank's frames: the local pipeline, integer histograms and the per-frame series left on the device ----
-    if (T_local > 0) {
+    auto local = [&]() -> int {
+        if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+        int t0 = 0, t1 = 0;
+        WOL_TRY(wol_shard_bounds(T_total, comm->rank, comm->world, &t0, &t1));
+        if (T_local != t1 - t0)
+            return fail(WOL_ERR_INVALID, "q_traj_sharded: rank %d of %d owns frames [%d, %d) of %d, got %d frames", comm->rank,
+                        comm->world, t0, t1, T_total, T_local);
+        if (qhist && qbins <= 0) return fail(WOL_ERR_INVALID, "qbins must be > 0");
+        if (dhist && (dbins <= 0 || !(dbinwidth > 0.0))) return fail(WOL_ERR_INVALID, "dbins/dbinwidth must be > 0");
+        if (T_local <= 0) return WOL_OK;
         if (host) {
             std::vector<int64_t> hq((size_t)std::max(qbins, 1), 0), hd((size_t)std::max(dbins, 1), 0);
             std::vector<double> hm((size_t)T_local), hv((size_t)T_local);
@@ -1994,7 +2073,7 @@ int q_traj_sharded_impl(wol_ctx* c, wol_comm* comm, const T* frames, int64_t ato
             std::vector<double> mv(2 * (size_t)per, 0.0);
             for (int t = 0; t < T_local; ++t) { mv[2 * (size_t)t] = hm[(size_t)t]; mv[2 * (size_t)t + 1] = hv[(size_t)t]; }
             if (qhist) HIP_TRY(hipMemcpyAsync(d_hist, hq.data(), sizeof(int64_t) * (size_t)qbins, hipMemcpyHostToDevice, c->stream));
-            if (dhist) HIP_TRY(hipMemcpyAsync(d_hist + (qhist ? qbins : 0), hd.data(), sizeof(int64_t) * (size_t)dbins, hipMemcpyHostToDevice, c->stream));
+            if (dhist) HIP_TRY(hipMemcpyAsync(d_hist + nq, hd.data(), sizeof(int64_t) * (size_t)dbins, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(d_mine, mv.data(), sizeof(double) * mv.size(), hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));   // the host vectors above go out of scope
         } else {
@@ -2003,16 +2082,34 @@ int q_traj_sharded_impl(wol_ctx* c, wol_comm* comm, const T* frames, int64_t ato
             double* sm = c->cvt_out[3].as<double>();
             WOL_TRY((q_traj_impl<T>(c, frames, atom_stride, frame_stride, T_local, n, boxes, low, high, sm, sm + T_local,
                                     qhist ? reinterpret_cast<int64_t*>(d_hist) : nullptr, qbins,
-                                    dhist ? reinterpret_cast<int64_t*>(d_hist + (qhist ? qbins : 0)) : nullptr, dbins, dbinwidth,
+                                    dhist ? reinterpret_cast<int64_t*>(d_hist + nq) : nullptr, dbins, dbinwidth,
                                     q_out, mem)));
             HIP_TRY(hipMemcpy2DAsync(d_mine, 2 * sizeof(double), sm, sizeof(double), sizeof(double), (size_t)T_local, hipMemcpyDeviceToDevice, c->stream));
             HIP_TRY(hipMemcpy2DAsync(d_mine + 1, 2 * sizeof(double), sm + T_local, sizeof(double), sizeof(double), (size_t)T_local, hipMemcpyDeviceToDevice, c->stream));
         }
+        return WOL_OK;
+    };
+    const int local_rc = local();
+    const std::string local_msg = g_err;
+    if (local_rc != WOL_OK) {
+        // nothing half-done goes into the sums: zeros and a raised status word instead
+        (void)hipGetLastError();
+        HIP_TRY(hipMemsetAsync(xb, 0, o_all, c->stream));
+        const unsigned long long one = 1ull;
+        HIP_TRY(hipMemcpyAsync(d_status, &one, sizeof one, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    // ---- the exchange step: integer sums (order-independent, so the result is the one-GPU result bit for bit) and
-    //      the gathered per-frame series; KB-sized, latency-bound ----
-    if (nh > 0) NCCL_TRY(g_rccl.AllReduce(d_hist, d_hist, (size_t)nh, ncclUint64, ncclSum, comm->comm, c->stream));
+    // ---- the exchange step: integer sums (order-independent, so the result is the one-GPU result bit for bit; the last
+    //      word counts the ranks whose local part failed) and the gathered per-frame series; KB-sized, latency-bound ----
+    NCCL_TRY(g_rccl.AllReduce(d_hist, d_hist, (size_t)nh + 1, ncclUint64, ncclSum, comm->comm, c->stream));
     if (mean || var) NCCL_TRY(g_rccl.AllGather(d_mine, d_all, 2 * (size_t)per, ncclFloat64, comm->comm, c->stream));
+    // the agreed status is a host decision (one word; the call synchronises here in either memory mode)
+    unsigned long long failed = 0;
+    HIP_TRY(hipMemcpyAsync(&failed, d_status, sizeof failed, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (local_rc != WOL_OK) { g_err = local_msg; return local_rc; }
+    if (failed != 0)
+        return fail(WOL_ERR_PEER, "q_traj_sharded: %llu of %d ranks failed in their local part; no result was written", failed, W);
     // ---- results to the caller: histograms ACCUMULATE into its arrays (as wol_q_traj), series in frame order ----
     if (host) {
         std::vector<unsigned long long> hh((size_t)std::max(nh, 1));
@@ -2021,7 +2118,7 @@ int q_traj_sharded_impl(wol_ctx* c, wol_comm* comm, const T* frames, int64_t ato
         if (mean || var) HIP_TRY(hipMemcpyAsync(all.data(), d_all, sizeof(double) * all.size(), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (qhist) for (int k = 0; k < qbins; ++k) qhist[k] += (int64_t)hh[(size_t)k];
-        if (dhist) for (int k = 0; k < dbins; ++k) dhist[k] += (int64_t)hh[(size_t)(qhist ? qbins : 0) + k];
+        if (dhist) for (int k = 0; k < dbins; ++k) dhist[k] += (int64_t)hh[(size_t)nq + k];
         for (int r = 0; r < W && (mean || var); ++r) {
             int a = 0, b = 0;
             (void)wol_shard_bounds(T_total, r, W, &a, &b);
@@ -2033,7 +2130,7 @@ int q_traj_sharded_impl(wol_ctx* c, wol_comm* comm, const T* frames, int64_t ato
     } else {
         if (qhist) hipLaunchKernelGGL(k_add_u64, dim3((qbins + 255) / 256), dim3(256), 0, c->stream, d_hist,
                                       reinterpret_cast<unsigned long long*>(qhist), qbins);
-        if (dhist) hipLaunchKernelGGL(k_add_u64, dim3((dbins + 255) / 256), dim3(256), 0, c->stream, d_hist + (qhist ? qbins : 0),
+        if (dhist) hipLaunchKernelGGL(k_add_u64, dim3((dbins + 255) / 256), dim3(256), 0, c->stream, d_hist + nq,
                                       reinterpret_cast<unsigned long long*>(dhist), dbins);
         for (int r = 0; r < W && (mean || var); ++r) {
             int a = 0, b = 0;

@@ -515,6 +515,34 @@ k_search_fast(FastArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Diagnostic (context option "check_proposals"): the row kernel is trusted to write a key for EVERY water of every tile it
+// is given -- a stale key from an earlier batch would pass a certification that proves "these four are close", not "these
+// are the four closest".  With the option on the host poisons prop / prop_key before the proposal kernel; this kernel
+// then counts the keys that were written and the proposals that name a slot outside the frame, and turns keys still
+// poisoned into "not certifiable" so that a violated invariant is reported instead of gathered through.
+// ---------------------------------------------------------------------------------------------
+#define WOL_PROP_POISON 0x7E7E7E7E
+__global__ void __launch_bounds__(256)
+k_check_props(int* __restrict__ prop_key, const int4* __restrict__ prop, int64_t total, int n, unsigned long long* __restrict__ counters) {
+    unsigned long long written = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = prop_key[i];
+        if (k == WOL_PROP_POISON) { prop_key[i] = -1; continue; }
+        ++written;
+        if (k >= 0) {
+            const int4 p = prop[i];
+            if ((unsigned)p.x >= (unsigned)n || (unsigned)p.y >= (unsigned)n || (unsigned)p.z >= (unsigned)n || (unsigned)p.w >= (unsigned)n) ++bad;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { written += __shfl_xor(written, off, 64); bad += __shfl_xor(bad, off, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        if (written) atomicAdd(&counters[0], written);
+        if (bad) atomicAdd(&counters[1], bad);
+    }
+}
+
 // radius around a water inside which the proposal kernel is guaranteed to have seen every water: one cell
 // width plus the distance to the nearest wall of its cell -- along x of its fine bin when the proposals
 // come from k_search_rows, whose x window is counted in bins (fp32 binning there vs fp64 here: 1e-5 A margin)

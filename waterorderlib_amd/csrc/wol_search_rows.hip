@@ -6,12 +6,14 @@
 //
 //   tile   = sx cells along x by ry cell rows along y in ONE z layer (long in x: whole rows if they fit);
 //   staged = for every y row of the tile and its two y-halo rows, the three z rows (z-1, z, z+1) MERGED
-//            into one array ordered by a fine x bin (WOL_XSUB bins per cell) -- a "triple".  A wave per
-//            staged row reads the row's three contiguous pieces of the cell-sorted fp32 array (left halo
-//            cell, the tile's cells, right halo cell; periodic images come out shifted because the
-//            coordinates are built from staged cell numbers), counts into LDS bin counters with a
-//            returning atomic (= rank inside the bin), a scan turns counts into starts, a second pass
-//            over the same (L2-hot) rows places every water.  Pair records as in k_search_fast.
+//            into one array ordered by a fine x bin (WOL_XSUB bins per cell) -- a "triple".  The rows arrive
+//            bin-sorted from k_sort_in_row: every water's fp32 record carries its cell, sub-bin and rank inside
+//            the bin, cnt4[] the four sub-bin populations of every cell.  One pass, no atomics: a wave per triple
+//            turns the three rows' cnt4 words into the first entry of every merged bin (wave scan) and the number
+//            of waters of the rows below per bin; a wave per staged row then reads the row's three contiguous
+//            pieces (left halo cell, the tile's cells, right halo cell; periodic images come out shifted because
+//            the coordinates are built from staged cell numbers) and places every water at
+//            first entry of its bin + waters of the rows below + its own rank.  Pair records as in k_search_fast.
 //   sweep  = a water in row y looks at THREE contiguous windows, the bins [b-XSUB, b+XSUB] of triples
 //            y-1, y, y+1 (b = its own fine bin): an x reach of at least one cell width plus the distance
 //            to its bin wall, against nine spans of three whole cells before -- 25 % fewer candidates,
@@ -40,7 +42,9 @@
 #define WOL_ROWS_MAXTRIP (WOL_ROWS_MAXRY + 2)
 #define WOL_ROWS_MAXROWS (3 * WOL_ROWS_MAXTRIP)
 #define WOL_ROWS_MAXSX (252 / WOL_XSUB - 2)   // (sx + 2) * XSUB bins <= 252 (four bins per lane in the scan)
+#ifndef WOL_ROWS_BINW
 #define WOL_ROWS_BINW 704      // 32-bit words of bin counters: sum over the triples of ceil((bins + 1) / 2)
+#endif
 #define WOL_SLOT_BITS 20       // record id word = entry << 20 | sorted slot (frames of up to 2^20 waters)
 #ifndef WOL_ROWS_ROUNDS
 #define WOL_ROWS_ROUNDS 1      // sweep rounds per wave a tile is sized for (experiments: 2 = tiles twice as tall)
@@ -164,6 +168,11 @@ k_search_rows(FastArgs a) {
     const bool dyn = a.work != nullptr;
     int* __restrict__ ctr = dyn ? a.work + (aff ? 16 * (int)(blockIdx.x & 7) : 0) : nullptr;
     int w_next = 0, w_base = 0;   // next number drawn; first number of frame f (the numbers run through the XCD's frames)
+    // s_flag ("this tile overflows its tables: exact path") is raised by several waves during a tile's table phase and read
+    // by everybody behind that phase's last barrier; it is cleared where no wave can be raising it: here, and by thread 0
+    // during the sweep (every thread has read it before the barrier in front of the sweep, and the next tile's first
+    // barrier orders the clear before that tile's table phase)
+    if (tid == 0) s_flag = 0;
     if (dyn) {
         if (tid == 0) s_next = atomicAdd(ctr, 1);
         __syncthreads();
@@ -220,7 +229,6 @@ k_search_rows(FastArgs a) {
         //      every fine bin of the merged triple (bins[], 16-bit) and, per bin, how many waters of the rows below
         //      precede a row's own (obins[]: bytes).  The rows are bin-sorted and every record carries its rank inside its
         //      bin, so these tables place a staged water without any counting pass. ----
-        if (tid == 0) s_flag = 0;
         if (tid < nrows) {
             const int t = (int)(((float)tid + 0.5f) * (1.0f / 3.0f)), dzk = tid - 3 * t;
             const int gz = wol_wrap_cell(cz + dzk - 1, nz), gy = wol_wrap_cell(y0 + t - 1, ny);
@@ -401,6 +409,7 @@ k_search_rows(FastArgs a) {
         }
         __syncthreads();
         WOL_STAMP(4);
+        if (tid == 0) s_flag = 0;   // (for the next tile: see the note at the kernel's first clear)
         // ---- sweep: one lane per own water, three windows ----
         const int nq = qrow[re];
         for (int qb = wave * 64; qb < nq; qb += WOL_ROWS_BLOCK) {
