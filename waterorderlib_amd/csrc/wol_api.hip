@@ -452,16 +452,27 @@ struct HistArgs {
     double dbinwidth = 0.0;
 };
 
-// Runs the q pipeline on F device-resident frames (views already point at device memory).
-// out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
+// What the sort stage of a batch leaves behind for the kernels that consume it.
+struct BatchPlan {
+    wol_ctx::SortSet* S = nullptr;     // the set of intermediate arrays this batch owns (null: no frame took the cell path)
+    FrameGrid* gh = nullptr;           // host copy of the per-frame grids
+    int n_cell_frames = 0;
+    std::vector<int> brute_frames;     // frames without a grid (non-periodic axis, tiny inputs, forced): all-pairs kernels
+    bool use_fast = false, rows_kernel = false, level_early = false, pipe = false;
+    int rows_block = 0, tiles_max = 0;
+    float4* s32 = nullptr;
+    unsigned* cnt4 = nullptr;
+    hipStream_t ss = nullptr, qs = nullptr;   // the streams of the sort and of the proposal kernel
+};
+
+// Sort stage of a batch of F device-resident frames: per-frame grids (cells of `cell_width`, walks sized for `reach`),
+// the cell sort in whichever form the batch shape calls for, and -- when the fp32-filtered q path will consume the batch
+// (want_fast) -- the fine-bin order, the fp32 copy and the density levels it needs.  Everything is enqueued; on return
+// bp->S holds cell-sorted fp64 records (sorted), cell_start (cells) and the grids on the device.
 template <typename T>
-int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
-                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0) {
+int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, double cell_width, double reach,
+               bool want_fast, bool force_brute, int allow_pipe, BatchPlan* bp) {
     const int n = fv.n;
-    c->stat_slots = 0;   // (set again below when the certification kernel keeps per-wave partial sums)
-    if (F <= 0 || ns <= 0) return WOL_OK;
-    const double lowsq = low * low, highsq = high * high;
-    const size_t hist_lds = (size_t)((out.qhist ? out.qbins : 0) + (out.dhist ? out.dbins : 0)) * sizeof(int);
 
     // --- per-frame grids (host) ---
     if (c->grid_copy_pending) {  // the pinned staging buffer is still being read by an earlier upload
@@ -472,14 +483,15 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     FrameGrid* gh = c->grids_host.as<FrameGrid>();
     int64_t cell_total = 0;
     int n_cell_frames = 0;
-    std::vector<int> brute_frames;
-    const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
+    std::vector<int>& brute_frames = bp->brute_frames;
+    brute_frames.clear();
+    const double high = reach;
     int rows_block = c->force_rows_block;   // the k_search_rows instantiation of this batch: forced, or the first frame's choice
     for (int f = 0; f < F; ++f) {
-        bool ok = !force_brute && make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f], rows_block);
+        bool ok = !force_brute && make_grid(boxes_host + 3 * (size_t)f, n, cell_width, high, &gh[f], rows_block);
         if (ok && rows_block == 0) rows_block = gh[f].row_block;
         if (!ok) {
-            make_grid(boxes_host + 3 * (size_t)f, n, c->cell_width, high, &gh[f], rows_block);
+            make_grid(boxes_host + 3 * (size_t)f, n, cell_width, high, &gh[f], rows_block);
             gh[f].maxshell = -1;  // search kernel skips this frame
             gh[f].ncell = 1;
             for (int k = 0; k < 3; ++k) gh[f].nc[k] = 1;
@@ -544,7 +556,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         HIP_TRY(hipEventRecord(c->grid_ev, c->grid_stream));
         HIP_TRY(hipStreamWaitEvent(ss, c->grid_ev, 0));
         c->grid_copy_pending = true;
-        bool use_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
+        bool use_fast = want_fast;
         int tiles_max = 0;
         // the row-merged proposal kernel needs the rows bin-sorted by k_sort_in_row: rows of up to WOL_L2_MAXNX cells
         bool rows_kernel = c->search_rows && n <= (1 << WOL_SLOT_BITS);
@@ -751,6 +763,38 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             HIP_TRY(hipStreamWaitEvent(use_fast ? qs : c->stream, S.sorted_ev, 0));
         }
         c->last_set = &S;
+        bp->S = &S;
+        bp->use_fast = use_fast; bp->rows_kernel = rows_kernel; bp->level_early = level_early; bp->pipe = pipe;
+        bp->tiles_max = tiles_max; bp->s32 = s32; bp->cnt4 = cnt4; bp->ss = ss; bp->qs = qs;
+    }
+    bp->gh = gh;
+    bp->n_cell_frames = n_cell_frames;
+    bp->rows_block = rows_block;
+    return WOL_OK;
+}
+
+// Runs the q pipeline on F device-resident frames (views already point at device memory).
+// out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
+template <typename T>
+int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
+                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0) {
+    const int n = fv.n;
+    c->stat_slots = 0;   // (set again below when the certification kernel keeps per-wave partial sums)
+    if (F <= 0 || ns <= 0) return WOL_OK;
+    const double lowsq = low * low, highsq = high * high;
+    const size_t hist_lds = (size_t)((out.qhist ? out.qbins : 0) + (out.dhist ? out.dbins : 0)) * sizeof(int);
+    const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
+    const bool want_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
+    BatchPlan bp;
+    WOL_TRY(sort_batch<T>(c, fv, F, boxes_host, c->cell_width, high, want_fast, force_brute, allow_pipe, &bp));
+    const std::vector<int>& brute_frames = bp.brute_frames;
+    if (bp.n_cell_frames > 0) {
+        wol_ctx::SortSet& S = *bp.S;
+        const bool use_fast = bp.use_fast, rows_kernel = bp.rows_kernel, level_early = bp.level_early, pipe = bp.pipe;
+        const int rows_block = bp.rows_block, tiles_max = bp.tiles_max;
+        float4* s32 = bp.s32;
+        unsigned* cnt4 = bp.cnt4;
+        hipStream_t qs = bp.qs;
 
         SearchArgs a;
         a.grids = S.grids.as<FrameGrid>();
@@ -821,7 +865,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             if (rows_kernel && c->check_props) {
                 hipLaunchKernelGGL(k_check_props, dim3(1024), dim3(256), 0, qs, S.prop_key.as<int>(), S.prop.as<int4>(), (int64_t)F * n, n,
                                    c->prop_counters.as<unsigned long long>());
-                c->prop_expected += (int64_t)n_cell_frames * n;
+                c->prop_expected += (int64_t)bp.n_cell_frames * n;
             }
             if (pipe && qs != c->stream) {   // the certification stage follows on the caller-visible stream
                 HIP_TRY(hipEventRecord(S.searched_ev, qs));
