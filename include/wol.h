@@ -77,7 +77,11 @@ int wol_ctx_synchronize(wol_ctx* ctx);
  * fill, default; 512 / 768 = force that k_search_rows instantiation: tests and tuning), "check_proposals" (diagnostic, 0/1:
  * the proposal arrays are poisoned before the row-merged proposal kernel and a counting kernel behind it checks that the
  * kernel wrote a key for every water it was given -- counters "proposals_written", "proposals_expected", "proposals_bad";
- * switching it on or off restarts the counters) */
+ * switching it on or off restarts the counters), "host_pack" (what host-memory frames cross the link as: 0 = whole
+ * interleaved frames, one linear copy per batch; 1 = the O rows only, packed by host threads into pinned staging -- what
+ * the reference's caller does with pos[watInds], orderParam_lib.py:1462; 2 = the same, as float32 whenever every coordinate
+ * of the batch is exactly a float32 -- bit-identical results at half the bytes; default 2), "host_threads" (packing
+ * threads, 0 = min(16, hardware threads)) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
@@ -220,6 +224,57 @@ int wol_q_traj_f32(wol_ctx* ctx, const float* frames, int64_t atom_stride, int64
                    int T, int n, const double* boxes, double lowcut, double highcut, double* mean,
                    double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,
                    double dbinwidth, float* q_out, int mem);
+
+/* ---- level 3, continued: populations, and the other two frame loops of the path --------------------------------
+ * tetOrderCalc, threeBodyCalc and lsiCalc all take `subInds`: per frame t and population j a list of atoms whose
+ * positions pos[subInds[t][j]] are handed to the per-frame routine as subPos (orderParam_lib.py:1464-1467, 1318-1322,
+ * 1624-1628).  Here a population is given the same way, by POSITION: pop_pos holds the query points of all frames and
+ * populations back to back ([total][3] reals of `dtype` in `mem`), points [pop_off[t * npops + j], pop_off[t * npops +
+ * j + 1]) belong to frame t, population j (pop_off: HOST array of T * npops + 1 offsets, pop_off[0] = 0).  npops = 0
+ * (pop_pos / pop_off NULL) = no populations.  A point that coincides with a water does not see itself (d^2 > lowcut^2),
+ * exactly as in the reference's subPos != Pos branch, so a population of water oxygens gets those waters' values.
+ * Results are laid out by SEGMENT: seg = t * (npops + 1) + j with j = 0 for all waters of frame t and j >= 1 for
+ * population j - 1.  `frames`, `pop_pos` and the real-valued per-water / per-point outputs are `dtype` arrays
+ * (WOL_F64 / WOL_F32: float storage is promoted exactly, the arithmetic is the fp64 path's) in `mem`; integer and
+ * double outputs live in `mem` too; boxes and pop_off are host arrays.  Frames are batched through HBM as in wol_q_traj
+ * (host frames: double-buffered staging, option "host_pack"). */
+
+/* tetOrderCalc with populations (orderParam_lib.py:1458-1495): everything wol_q_traj returns for population 0 (all
+ * waters) plus, per frame and population, np.mean / np.var of the population's q (pop_mean / pop_var [T][npops]; NaN
+ * for an empty population, as numpy), np.histogram(q, qbins, [0, 1]) of every population ACCUMULATED into
+ * pop_qhist[npops][qbins], and optionally every point's q (pop_q[total]).  Any output may be NULL. */
+int wol_q_traj_pops(wol_ctx* ctx, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
+                    const double* boxes, double lowcut, double highcut, double* mean, double* var, int64_t* qhist,
+                    int qbins, int64_t* dhist, int dbins, double dbinwidth, void* q_out, const void* pop_pos,
+                    const int64_t* pop_off, int npops, double* pop_mean, double* pop_var, int64_t* pop_qhist,
+                    void* pop_q, int dtype, int mem);
+
+/* threeBodyCalc's frame loop (orderParam_lib.py:1312-1353): per segment what wp.tetrahedralMetrics
+ * (water_properties.py:314-342) keeps of wp.getCosAngs's angles (:210-250; shell lowcut < d <= highcut, reference
+ * default 3.413): ang_hist[seg][nbins] = np.histogram(angles, nbins, [0, 180]) (written, not accumulated: sum over
+ * frames for the pooled distribution the reference writes to 3bDistribution_j.txt; the per-frame histogram gives the
+ * frame's entropy); counts[seg] = {number of angles, number of angles in [100, 120]}; cos_sums[seg] = {sum,
+ * sum of squares} of cos(angle * pi / 180) over the angles in [100, 120] (so fracTet = counts[1] / counts[0], avgCos =
+ * cos_sums[0] / counts[1], varCos = cos_sums[1] / counts[1] - avgCos^2).  The sums are accumulated as exact fixed-point
+ * integers: results do not depend on batching, scheduling or the order of the waters. */
+int wol_cos_angs_traj(wol_ctx* ctx, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
+                      const double* boxes, double lowcut, double highcut, const void* pop_pos, const int64_t* pop_off,
+                      int npops, int nbins, int64_t* ang_hist, int64_t* counts, double* cos_sums, int dtype, int mem);
+
+/* lsiCalc's frame loop (orderParam_lib.py:1618-1640): wp.getLSI (water_properties.py:252-311; shell lowcut < d <=
+ * highcut, "next" neighbour in (highcut, highcut + 3.7] chosen by raw distance as the reference does) per segment:
+ * counts[seg] = len(lsiVals) (waters the reference skips are not counted), mean[seg] / var[seg] = np.mean / np.var of
+ * them (NaN for none), lsi_hist[npops + 1][nbins] = np.histogram(lsiVals, nbins, [0, hist_max]) per population over
+ * all frames, ACCUMULATED (the reference: 500 bins over [0, 0.3]).  Optional: lsi_out[T][n] = LSI of every water in the
+ * caller's water order (NaN where the reference skips it), pop_lsi[total] likewise for the population points.
+ * The kernel keeps a water's shell in LDS rows sized for twice what the mean density predicts; denser shells (clusters) are
+ * finished from rows in global memory.  A shell of more than 1022 waters, or more than max(4096, waters per batch / 16)
+ * such waters in one batch, is reported as WOL_ERR_INVALID: use wol_lsi_frame for such inputs.  Both shell trajectory calls synchronise the stream once, at the
+ * end, to report that condition. */
+int wol_lsi_traj(wol_ctx* ctx, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
+                 const double* boxes, double lowcut, double highcut, const void* pop_pos, const int64_t* pop_off,
+                 int npops, int nbins, double hist_max, int64_t* lsi_hist, int64_t* counts, double* mean, double* var,
+                 void* lsi_out, void* pop_lsi, int dtype, int mem);
 
 /* ---- multi-GPU: frame shards, one exchange step ------------------------------------------
  * The frame loop of tetOrderCalc has no dependence between frames (orderParam_lib.py:1458-1473): rank r of R (one

@@ -268,11 +268,18 @@ def test_drivers(oracle, tmp_path, monkeypatch):
     assert tab.shape == (500, 2) and tab[:, 1].sum() == hists[0].sum()
     pTet, avgCos, varCos, ent, nW = opl.threeBodyCalc(obj, rng=np.random.default_rng(2))
     ang = np.concatenate([oracle.getCosAngs(O[t], O[t], boxes[t])[0] for t in range(5)])
-    np.testing.assert_allclose(np.sort(opl.threeBodyCalc.last_angles[0]), np.sort(ang), rtol=0, atol=ANG_TOL)
+    assert np.array_equal(opl.threeBodyCalc.last_hist[0], np.histogram(ang, bins=500, range=[0.0, 180.0])[0])
+    for t in range(5):
+        a_t = oracle.getCosAngs(O[t], O[t], boxes[t])[0]
+        tet = a_t[(a_t >= 100.0) & (a_t <= 120.0)]
+        assert abs(opl.threeBodyCalc.last_series["pTet"][0][t] - len(tet) / len(a_t)) < 1e-15
+        assert abs(opl.threeBodyCalc.last_series["avgCos"][0][t] - np.mean(np.cos(tet * np.pi / 180.0))) < 1e-12
     assert nW[0][0] == 1500 and 0.0 < pTet[0][0] < 1.0 and np.loadtxt("3bDistribution_0.txt").shape == (500, 2)
     avgL, varL = opl.lsiCalc(obj, rng=np.random.default_rng(3))
     l0 = [oracle.getLSI(O[t], O[t], boxes[t])[0] for t in range(5)]
     assert abs(avgL[0][0] - np.mean([np.mean(x) for x in l0])) < 1e-13
+    assert abs(varL[0][0] - np.mean([np.var(x) for x in l0])) < 1e-13
+    assert np.array_equal(opl.lsiCalc.last_hist[0], np.histogram(np.concatenate(l0), bins=500, range=[0.0, 0.3])[0])
     assert np.loadtxt("lsiDistribution_0.txt").shape == (500, 2)
 
 

@@ -204,3 +204,219 @@ def test_option_ranges_are_checked():
         with pytest.raises(_lib.WolError):
             c.set_option(key, bad)
     c.close()
+
+
+# ---- trajectory entries for the other two frame loops and for the populations -------------------------------------------
+def _traj_inputs(n=3000, T=5, len_wat=3, seed=31, npops=2):
+    from waterorderlib_amd import synth
+    xyz, boxes = synth.water_frames(n, T, seed=seed, len_wat=len_wat)
+    boxes = boxes * (1.0 + 0.01 * np.arange(T))[:, None]          # a box per frame
+    xyz = xyz * (1.0 + 0.01 * np.arange(T))[:, None, None]
+    rng = np.random.default_rng(seed)
+    O = np.ascontiguousarray(xyz[:, 0::len_wat])
+    pos, off = [], [0]
+    for t in range(T):
+        for j in range(npops):
+            if j == 0:
+                p = O[t][rng.choice(n, 150 + 10 * t, replace=False)]          # water oxygens (the usual populations)
+            elif t == 1:
+                p = np.zeros((0, 3))                                           # an empty population in one frame
+            else:
+                p = rng.random((40, 3)) * boxes[t] * 1.5 - 0.2 * boxes[t]      # arbitrary points, some outside the box
+            pos.append(p); off.append(off[-1] + len(p))
+    return xyz, boxes, O, np.concatenate(pos), np.asarray(off, dtype=np.int64)
+
+
+def _hist180(a, bins=500):
+    return np.histogram(a, bins=bins, range=[0.0, 180.0])[0].astype(np.int64)
+
+
+@pytest.mark.parametrize("form", ["host", "device", "f32"])
+def test_cos_angs_traj_equals_the_per_frame_chain(oracle, form):
+    """wol_cos_angs_traj per (frame, population) against wp.getCosAngs + wp.tetrahedralMetrics on the same frames:
+    integer histogram and counts exact (also against the oracle's angles), cosine sums and the derived statistics to
+    1e-12; TIP3P-interleaved frames, a box per frame, populations of water oxygens / arbitrary points / none"""
+    import torch
+    from waterorderlib_amd import engine
+    from waterorderlib_amd import water_properties as wp
+    xyz, boxes, O, pop_pos, pop_off = _traj_inputs()
+    if form == "f32":
+        xyz = xyz.astype(np.float32); pop_pos = pop_pos.astype(np.float32)
+        O = np.ascontiguousarray(xyz[:, 0::3]).astype(np.float64)
+    fr = torch.from_numpy(xyz).cuda() if form == "device" else xyz
+    res = engine.cos_angs_traj(fr, boxes, len_wat=3, pop_pos=pop_pos, pop_off=pop_off, npops=2)
+    g = (lambda a: a.cpu().numpy()) if form == "device" else (lambda a: a)
+    hist, counts, sums = g(res.hist), g(res.counts), g(res.cos_sums)
+    T = len(xyz)
+    for t in range(T):
+        for j in range(3):
+            sub = O[t] if j == 0 else pop_pos[pop_off[2 * t + j - 1]:pop_off[2 * t + j]].astype(np.float64)
+            ang = wp.getCosAngs(sub, O[t], boxes[t])[0] if len(sub) else np.zeros(0)
+            tag = "frame %d population %d" % (t, j)
+            assert np.array_equal(hist[t, j], _hist180(ang)), tag
+            tet = ang[(ang >= 100.0) & (ang <= 120.0)]
+            assert counts[t, j, 0] == len(ang) and counts[t, j, 1] == len(tet), tag
+            cs = np.cos(tet * np.pi / 180.0)
+            assert abs(sums[t, j, 0] - cs.sum()) < 1e-9 and abs(sums[t, j, 1] - (cs * cs).sum()) < 1e-9, tag
+            if len(ang) and form != "f32":
+                ang_o = oracle.getCosAngs(sub, O[t], boxes[t])[0]
+                assert np.array_equal(hist[t, j], _hist180(ang_o)), tag + " (oracle)"
+            if len(tet):
+                _, _, frac, avg, var, ent = wp.tetrahedralMetrics(ang)
+                h, a, b, c_, d = res.metrics(t, j)
+                assert abs(a - frac) < 1e-15 and abs(b - avg) < 1e-12 and abs(c_ - var) < 1e-12 and abs(d - ent) < 1e-12, tag
+
+
+def test_cos_angs_traj_golden_and_big_batches(oracle):
+    """the reference's own golden angles (gas512, ice512) binned; a 64-frame batch of 30 000 waters (streaming sort forms,
+    several blocks per frame) against the per-frame call; dense blobs whose shells outgrow the LDS rows"""
+    import torch
+    from conftest import golden
+    from waterorderlib_amd import engine, synth
+    from waterorderlib_amd import water_properties as wp
+    for name in ("gas512", "ice512"):
+        gd = golden(name)
+        res = engine.cos_angs_traj(gd["pos"][None], gd["box"][None])
+        assert np.array_equal(res.hist[0, 0], _hist180(gd["cos_ang"])), name
+        assert np.array_equal(res.hist[0, 0], gd["ang_hist"].astype(np.int64)), name     # the reference's own np.histogram
+        assert res.counts[0, 0, 0] == len(gd["cos_ang"])
+        lr = engine.lsi_traj(gd["pos"][None], gd["box"][None], want_lsi=True)
+        vals = lr.lsi[0][~np.isnan(lr.lsi[0])]
+        np.testing.assert_allclose(vals, gd["lsi"], rtol=0, atol=1e-13, err_msg=name)
+        assert lr.counts[0, 0] == len(gd["lsi"])
+    n, T = 30000, 64
+    base, box = synth.lattice_sites(n, seed=4)
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    fr = (torch.from_numpy(base).cuda().unsqueeze(0) + 0.3 * torch.randn((T, n, 3), generator=g, device="cuda", dtype=torch.float64)).contiguous()
+    res = engine.cos_angs_traj(fr, np.tile(box[None], (T, 1)))
+    for t in (0, 37, 63):
+        ang = wp.getCosAngs(fr[t].cpu().numpy(), fr[t].cpu().numpy(), box)[0]
+        assert np.array_equal(res.hist[t, 0].cpu().numpy(), _hist180(ang))
+    # blobs: shells of hundreds of waters (listed again by the slow kernel), long highCut
+    rng = np.random.default_rng(5)
+    bx = np.array([40.0, 38.0, 42.0])
+    pos = rng.random((3, 2500, 3)) * bx
+    pos[:, :300] = bx * 0.5 + rng.normal(0.0, 1.2, size=(3, 300, 3))
+    res = engine.cos_angs_traj(pos, np.tile(bx[None], (3, 1)), highCut=3.0)
+    for t in range(3):
+        ang = wp.getCosAngs(pos[t], pos[t], bx, 0.0, 3.0)[0]
+        assert np.array_equal(res.hist[t, 0], _hist180(ang)) and res.counts[t, 0, 0] == len(ang)
+
+
+@pytest.mark.parametrize("form", ["host", "device", "f32"])
+def test_lsi_traj_equals_the_per_frame_chain(oracle, form):
+    """wol_lsi_traj against wp.getLSI per frame and population: per-water LSI bit for bit (NaN where the reference skips
+    the water), len(lsiVals), np.mean / np.var to 1e-14, the pooled 500-bin histogram over [0, 0.3] exact"""
+    import torch
+    from waterorderlib_amd import engine
+    from waterorderlib_amd import water_properties as wp
+    xyz, boxes, O, pop_pos, pop_off = _traj_inputs(seed=32)
+    if form == "f32":
+        xyz = xyz.astype(np.float32); pop_pos = pop_pos.astype(np.float32)
+        O = np.ascontiguousarray(xyz[:, 0::3]).astype(np.float64)
+    fr = torch.from_numpy(xyz).cuda() if form == "device" else xyz
+    res = engine.lsi_traj(fr, boxes, len_wat=3, pop_pos=pop_pos, pop_off=pop_off, npops=2, want_lsi=True, want_pop_lsi=True)
+    g = (lambda a: a.cpu().numpy()) if form == "device" else (lambda a: a)
+    hist, counts, mean, var, lsi, plsi = (g(a) for a in (res.hist, res.counts, res.mean, res.var, res.lsi, res.pop_lsi))
+    pooled = np.zeros((3, 500), dtype=np.int64)
+    for t in range(len(xyz)):
+        for j in range(3):
+            sub = O[t] if j == 0 else pop_pos[pop_off[2 * t + j - 1]:pop_off[2 * t + j]].astype(np.float64)
+            tag = "frame %d population %d" % (t, j)
+            if len(sub) == 0:
+                assert counts[t, j] == 0 and np.isnan(mean[t, j]) and np.isnan(var[t, j]), tag
+                continue
+            full = wp.getLSI(sub, O[t], boxes[t], full=True)[0]
+            vals = full[~np.isnan(full)]
+            mine = lsi[t] if j == 0 else plsi[pop_off[2 * t + j - 1]:pop_off[2 * t + j]]
+            if form == "f32":
+                np.testing.assert_allclose(mine.astype(np.float64), full, rtol=1e-6, atol=0, equal_nan=True, err_msg=tag)
+            else:
+                assert np.array_equal(mine, full, equal_nan=True), tag
+                if j == 0:
+                    np.testing.assert_allclose(vals, oracle.getLSI(sub, O[t], boxes[t])[0], rtol=0, atol=1e-13)
+            assert counts[t, j] == len(vals), tag
+            assert abs(mean[t, j] - np.mean(vals)) < 1e-14 and abs(var[t, j] - np.var(vals)) < 1e-14, tag
+            pooled[j] += np.histogram(vals, bins=500, range=[0.0, 0.3])[0]
+    assert np.array_equal(hist, pooled)
+
+
+def test_lsi_traj_with_shells_of_dozens_and_hundreds_of_waters():
+    """shells that outgrow the LDS rows (a long highCut: ~40 waters; a blob: hundreds) take the slow kernel's global rows:
+    the same values as wp.getLSI, bit for bit"""
+    from waterorderlib_amd import engine, synth
+    from waterorderlib_amd import water_properties as wp
+    xyz, boxes = synth.water_frames(2000, 3, seed=8)
+    res = engine.lsi_traj(xyz, boxes, highCut=6.5, want_lsi=True)
+    for t in range(3):
+        full = wp.getLSI(xyz[t], xyz[t], boxes[t], highCut=6.5, full=True)[0]
+        assert np.array_equal(res.lsi[t], full, equal_nan=True)
+        assert res.counts[t, 0] == int((~np.isnan(full)).sum())
+    rng = np.random.default_rng(6)
+    bx = np.array([40.0, 38.0, 42.0])
+    pos = rng.random((2, 2500, 3)) * bx
+    pos[:, :300] = bx * 0.5 + rng.normal(0.0, 1.5, size=(2, 300, 3))
+    res = engine.lsi_traj(pos, np.tile(bx[None], (2, 1)), want_lsi=True)
+    for t in range(2):
+        full = wp.getLSI(pos[t], pos[t], bx, full=True)[0]
+        assert np.array_equal(res.lsi[t], full, equal_nan=True)
+
+
+@pytest.mark.parametrize("form", ["host", "device", "f32"])
+def test_q_traj_pops_equals_the_per_frame_calls(oracle, form):
+    """wol_q_traj_pops: population 0 as wol_q_traj; every population point's q bit for bit that of wp.getOrderParamq(subPos,
+    watPos) (and the oracle's to 1e-12), np.mean / np.var per frame, the histograms exact; an empty population gives NaN"""
+    import torch
+    from waterorderlib_amd import engine
+    from waterorderlib_amd import water_properties as wp
+    xyz, boxes, O, pop_pos, pop_off = _traj_inputs(seed=33)
+    if form == "f32":
+        xyz = xyz.astype(np.float32); pop_pos = pop_pos.astype(np.float32)
+        O = np.ascontiguousarray(xyz[:, 0::3]).astype(np.float64)
+    fr = torch.from_numpy(xyz).cuda() if form == "device" else xyz
+    res = engine.tet_order_traj_pops(fr, boxes, pop_pos, pop_off, 2, len_wat=3, want_pop_q=True, want_dhist=True)
+    ref = engine.tet_order_traj(fr, boxes, len_wat=3)
+    g = (lambda a: a.cpu().numpy()) if form == "device" else (lambda a: a)
+    assert np.array_equal(g(res.qhist), g(ref.qhist)) and np.array_equal(g(res.dhist), g(ref.dhist))
+    assert np.array_equal(g(res.mean), g(ref.mean)) and np.array_equal(g(res.var), g(ref.var))
+    pm, pv, pqh, pq = (g(a) for a in (res.pop_mean, res.pop_var, res.pop_qhist, res.pop_q))
+    hist = np.zeros((2, 500), dtype=np.int64)
+    for t in range(len(xyz)):
+        for j in range(2):
+            sub = pop_pos[pop_off[2 * t + j]:pop_off[2 * t + j + 1]].astype(np.float64)
+            tag = "frame %d population %d" % (t, j + 1)
+            if len(sub) == 0:
+                assert np.isnan(pm[t, j]) and np.isnan(pv[t, j]), tag
+                continue
+            q = wp.getOrderParamq(sub, O[t], boxes[t])
+            mine = pq[pop_off[2 * t + j]:pop_off[2 * t + j + 1]]
+            if form == "f32":
+                np.testing.assert_allclose(mine.astype(np.float64), q, rtol=0, atol=1e-6, err_msg=tag)
+            else:
+                assert np.array_equal(mine, q), tag
+                np.testing.assert_allclose(q, oracle.getOrderParamq(sub, O[t], boxes[t]), rtol=0, atol=Q_TOL)
+            assert abs(pm[t, j] - np.mean(q)) < 1e-13 and abs(pv[t, j] - np.var(q)) < 1e-13, tag
+            hist[j] += np.histogram(q, bins=500, range=[0.0, 1.0])[0]
+    assert np.array_equal(pqh, hist)
+
+
+def test_pops_and_shell_trajectories_on_frames_without_a_grid(oracle):
+    """a non-periodic axis (BoxL < 0, waterlib.f90:41) and frames of a few hundred waters (all-pairs path): the trajectory
+    entries fall back to all-pairs walks over the frame with the same results as the per-frame calls"""
+    from waterorderlib_amd import engine
+    from waterorderlib_amd import water_properties as wp
+    rng = np.random.default_rng(12)
+    box = np.array([22.0, 25.0, -1.0])
+    pos = rng.random((3, 700, 3)) * np.array([22.0, 25.0, 30.0])
+    boxes = np.tile(box[None], (3, 1))
+    sub = [pos[t][rng.choice(700, 60, replace=False)] for t in range(3)]
+    pop_pos = np.concatenate(sub); pop_off = np.arange(4, dtype=np.int64) * 60
+    r = engine.tet_order_traj_pops(pos, boxes, pop_pos, pop_off, 1, want_pop_q=True)
+    ca = engine.cos_angs_traj(pos, boxes, pop_pos=pop_pos, pop_off=pop_off, npops=1)
+    ls = engine.lsi_traj(pos, boxes, pop_pos=pop_pos, pop_off=pop_off, npops=1, want_lsi=True)
+    for t in range(3):
+        assert np.array_equal(r.pop_q[60 * t:60 * t + 60], wp.getOrderParamq(sub[t], pos[t], box))
+        ang = wp.getCosAngs(pos[t], pos[t], box)[0]
+        assert np.array_equal(ca.hist[t, 0], _hist180(ang))
+        assert np.array_equal(ca.hist[t, 1], _hist180(wp.getCosAngs(sub[t], pos[t], box)[0]))
+        assert np.array_equal(ls.lsi[t], wp.getLSI(pos[t], pos[t], box, full=True)[0], equal_nan=True)

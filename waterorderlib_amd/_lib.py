@@ -26,7 +26,8 @@ SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy",
            "wol_wat_orient", "wol_wat_oh_vec", "wol_general_hbonds", "wol_general_hbonds_list",
            "wol_q_frame_t", "wol_cos_angs_t", "wol_lsi_frame_t",
            "wol_shard_bounds", "wol_comm_unique_id", "wol_comm_init", "wol_comm_adopt", "wol_comm_destroy",
-           "wol_q_traj_sharded", "wol_q_traj_sharded_f32"]
+           "wol_q_traj_sharded", "wol_q_traj_sharded_f32",
+           "wol_q_traj_pops", "wol_cos_angs_traj", "wol_lsi_traj"]
 
 _lib = None
 
@@ -130,6 +131,12 @@ def load():
                C.c_int, _vp, C.c_int, C.c_double, _vp, C.c_int]
     L.wol_q_traj_sharded.argtypes = sharded
     L.wol_q_traj_sharded_f32.argtypes = sharded
+    L.wol_q_traj_pops.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, _vp,
+                                  C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int]
+    L.wol_cos_angs_traj.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, C.c_int,
+                                    C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]
+    L.wol_lsi_traj.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, C.c_int,
+                               C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]
     _lib = L
     return L
 

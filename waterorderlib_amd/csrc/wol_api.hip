@@ -4,6 +4,7 @@
 #include "wol_search_fast.hip"
 #include "wol_search_rows.hip"
 #include "wol_shell.hip"
+#include "wol_shell_traj.hip"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only: the library is resolved at run time (wol_comm_*), never linked
@@ -13,7 +14,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wol.h"
@@ -134,6 +137,10 @@ struct wol_ctx {
     // host-trajectory pipeline (wol_q_traj with WOL_MEM_HOST): two staging sets; the copy of batch k+1 runs on
     // copy_stream under batch k's kernels
     DevBuf host_stage[2];
+    PinBuf pack_stage[2];           // pinned staging of the host-side O-row packer
+    int host_pack = 2;              // what host frames cross the link as: 0 whole frames, 1 packed O rows, 2 packed + float32 when exact
+    int host_threads = 0;           // packing threads (0 = min(16, hardware threads))
+    DevBuf pop_off, pop_pts, pop_stat, pop_hist, pop_out, pop_res;   // populations of a trajectory call; results of the shell trajectory calls
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied_ev[2] = {nullptr, nullptr}, consumed_ev[2] = {nullptr, nullptr};
     double last_h2d_bytes = 0.0;   // bytes the last host-trajectory call moved over the link (diagnostic counter)
@@ -471,7 +478,7 @@ struct BatchPlan {
 // bp->S holds cell-sorted fp64 records (sorted), cell_start (cells) and the grids on the device.
 template <typename T>
 int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, double cell_width, double reach,
-               bool want_fast, bool force_brute, int allow_pipe, BatchPlan* bp) {
+               bool want_fast, bool force_brute, int allow_pipe, BatchPlan* bp, bool need_set = false) {
     const int n = fv.n;
 
     // --- per-frame grids (host) ---
@@ -503,7 +510,7 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         cell_total += gh[f].ncell + 1;
     }
 
-    if (n_cell_frames > 0) {
+    if (n_cell_frames > 0 || need_set) {   // (need_set: frames without a grid still get their one-cell `sorted` copy)
         wol_ctx::SortSet& S = c->sets[c->next_set];
         c->next_set = (c->next_set + 1) % WOL_NSETS;
         // the sort goes to the second stream when this is a large device-resident batch (the trajectory
@@ -777,7 +784,7 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
 // out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
 template <typename T>
 int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
-                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0) {
+                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0, bool need_set = false) {
     const int n = fv.n;
     c->stat_slots = 0;   // (set again below when the certification kernel keeps per-wave partial sums)
     if (F <= 0 || ns <= 0) return WOL_OK;
@@ -786,7 +793,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
     const bool want_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
     BatchPlan bp;
-    WOL_TRY(sort_batch<T>(c, fv, F, boxes_host, c->cell_width, high, want_fast, force_brute, allow_pipe, &bp));
+    WOL_TRY(sort_batch<T>(c, fv, F, boxes_host, c->cell_width, high, want_fast, force_brute, allow_pipe, &bp, need_set));
     const std::vector<int>& brute_frames = bp.brute_frames;
     if (bp.n_cell_frames > 0) {
         wol_ctx::SortSet& S = *bp.S;
@@ -1067,10 +1074,240 @@ int check_ctx(wol_ctx* c) {
     return WOL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Frames of a trajectory call, batch by batch, as device-resident views.  Device frames: views into the caller's array.
+// Host frames: double-buffered staging; the copy of batch b + 1 crosses the link while batch b's kernels run.
+// What crosses the link (option "host_pack"):
+//   0  the frames as they lie in host memory, i.e. whole interleaved [O, H, H, EP] frames (one linear copy per batch);
+//   1  the O rows only: host threads (option "host_threads") pack the 24-byte rows the path reads -- what the reference's
+//      caller does with pos[watInds] (orderParam_lib.py:1462) -- into pinned staging, a quarter of a TIP4P frame's bytes;
+//   2  (default) the same, stored as float32 when EVERY coordinate of the batch is exactly representable as one (frames
+//      read from single-precision trajectory files are): promoted back exactly on the device, so results are bit for bit
+//      those of the fp64 frames at half the bytes again.  The first inexact value ends the attempt for the rest of the call.
+// Frames that are O-only already (atom stride 3) skip the packing unless narrowing applies.
+// ---------------------------------------------------------------------------------------------
+struct FrameBatchView {
+    const void* base = nullptr;   // device
+    bool f32 = false;             // element type of `base` (float or double)
+    int64_t atom_stride = 3, frame_stride = 0;
+};
+
+template <typename T>
+struct FrameFeeder {
+    wol_ctx* c = nullptr;
+    const T* frames = nullptr;
+    int64_t atom_stride = 3, frame_stride = 0;
+    int T_frames = 0, n = 0, Fb = 0, nbatch = 0;
+    bool host = false, pack = false, narrow = false;
+    std::vector<int> bstart;
+    bool batch_f32[2] = {false, false};
+
+    size_t batch_elems(int F) const { return (size_t)(F - 1) * frame_stride + (size_t)(n - 1) * atom_stride + 3; }
+
+    // batches of the call: Fb frames each (0 = automatic, bytes_per_water = intermediate device bytes a water costs)
+    int plan(wol_ctx* ctx, const T* fr, int64_t as, int64_t fs, int Tn, int nw, bool is_host, double bytes_per_water) {
+        c = ctx; frames = fr; atom_stride = as; frame_stride = fs; T_frames = Tn; n = nw; host = is_host;
+        pack = host && c->host_pack >= 1 && (atom_stride > 3 || (c->host_pack >= 2 && std::is_same<T, double>::value));
+        narrow = pack && c->host_pack >= 2 && std::is_same<T, double>::value;
+        Fb = c->frames_per_batch;
+        if (Fb <= 0) {
+            if (host) {
+                // host frames: batches of ~256 MB of link traffic (at least 64 frames: the streaming sort wants that many), so
+                // the first copy -- the only one no kernel runs under -- stays a small part of the job
+                const double frame_bytes = pack ? 3.0 * n * sizeof(T) : (double)frame_stride * sizeof(T);
+                Fb = (int)std::fmin(4096.0, std::fmax(64.0, 256.0e6 / frame_bytes));
+                const double per_frame = (double)n * bytes_per_water + 2.0 * frame_bytes;
+                Fb = (int)std::fmin((double)Fb, std::fmax(1.0, 6.0e9 / per_frame));
+            } else {
+                // device-resident frames: up to 125 M waters per batch (about 30 GB of intermediate arrays in three sets, of
+                // 288 GB) -- a 32-frame block of a million-water box is one batch, not 24 + 8
+                const double per_frame = (double)n * bytes_per_water;
+                Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 8.0e9 / per_frame));
+            }
+            if (Fb >= 8 && Fb < T_frames) Fb = (Fb / 8) * 8;
+        }
+        Fb = std::max(1, std::min(Fb, T_frames));
+        // batch b = frames [bstart[b], bstart[b + 1]).  Host frames: what the call costs beyond the copies is the kernels of
+        // the LAST batch (nothing crosses the link under them), so the tail of a several-batch call is cut off as a batch of
+        // its own of at most 32 frames
+        bstart.clear();
+        for (int f0 = 0; f0 < T_frames; f0 += Fb) bstart.push_back(f0);
+        bstart.push_back(T_frames);
+        if (host && c->frames_per_batch <= 0 && bstart.size() >= 3) {
+            const int last = T_frames - bstart[bstart.size() - 2];
+            if (last > 48) bstart.insert(bstart.end() - 1, T_frames - 32);
+        }
+        nbatch = (int)bstart.size() - 1;
+        return WOL_OK;
+    }
+
+    // the O rows of frames [f0, f0 + F) -> dst (packed [F][n][3]); narrowed to float when asked and exact.  Returns false
+    // when narrowing was asked for and a value is not a float (dst then holds garbage).
+    bool pack_rows(int f0, int F, void* dst, bool to_f32) const {
+        const int64_t rows = (int64_t)F * n;
+        int nt = c->host_threads > 0 ? c->host_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, rows / 4096));
+        std::atomic<bool> exact(true);
+        auto work = [&](int64_t r0, int64_t r1) {
+            int f = (int)(r0 / n);
+            int64_t w = r0 - (int64_t)f * n;
+            const T* src = frames + (int64_t)(f0 + f) * frame_stride + w * atom_stride;
+            bool ok = true;
+            if (to_f32) {
+                float* d = static_cast<float*>(dst) + 3 * r0;
+                for (int64_t r = r0; r < r1; ++r) {
+                    const float x = (float)src[0], y = (float)src[1], z = (float)src[2];
+                    ok = ok && ((T)x == src[0]) && ((T)y == src[1]) && ((T)z == src[2]);
+                    d[0] = x; d[1] = y; d[2] = z;
+                    d += 3; src += atom_stride;
+                    if (++w == n) { w = 0; ++f; src = frames + (int64_t)(f0 + f) * frame_stride; if (!ok) break; }
+                }
+            } else {
+                T* d = static_cast<T*>(dst) + 3 * r0;
+                for (int64_t r = r0; r < r1; ++r) {
+                    d[0] = src[0]; d[1] = src[1]; d[2] = src[2];
+                    d += 3; src += atom_stride;
+                    if (++w == n) { w = 0; ++f; src = frames + (int64_t)(f0 + f) * frame_stride; }
+                }
+            }
+            if (!ok) exact.store(false, std::memory_order_relaxed);
+        };
+        if (nt <= 1) {
+            work(0, rows);
+        } else {
+            std::vector<std::thread> th;
+            th.reserve((size_t)nt - 1);
+            for (int i = 1; i < nt; ++i) th.emplace_back(work, rows * i / nt, rows * (i + 1) / nt);
+            work(0, rows / nt);
+            for (auto& t : th) t.join();
+        }
+        return exact.load();
+    }
+
+    int enqueue_copy(int b) {
+        const int f0 = bstart[b], F = bstart[b + 1] - f0, k = b & 1;
+        if (!pack) {
+            if (b >= 2) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->consumed_ev[k], 0));   // batch b-2 is done with this set
+            HIP_TRY(hipMemcpyAsync(c->host_stage[k].p, frames + (int64_t)f0 * frame_stride, batch_elems(F) * sizeof(T),
+                                   hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(hipEventRecord(c->copied_ev[k], c->copy_stream));
+            c->last_h2d_bytes += (double)(batch_elems(F) * sizeof(T));
+            batch_f32[k] = !std::is_same<T, double>::value;
+            return WOL_OK;
+        }
+        // the pinned set is free once the copy that last read it (batch b - 2) has left it
+        if (b >= 2) HIP_TRY(hipEventSynchronize(c->copied_ev[k]));
+        bool as_f32 = !std::is_same<T, double>::value, packed = false;
+        if (narrow) {
+            if (pack_rows(f0, F, c->pack_stage[k].p, true)) { as_f32 = true; packed = true; }
+            else narrow = false;     // this trajectory is not single precision: stop trying
+        }
+        if (!packed) (void)pack_rows(f0, F, c->pack_stage[k].p, false);
+        const size_t bytes = (size_t)F * n * 3 * (as_f32 ? sizeof(float) : sizeof(T));
+        if (b >= 2) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->consumed_ev[k], 0));
+        HIP_TRY(hipMemcpyAsync(c->host_stage[k].p, c->pack_stage[k].p, bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->copied_ev[k], c->copy_stream));
+        c->last_h2d_bytes += (double)bytes;
+        batch_f32[k] = as_f32;
+        return WOL_OK;
+    }
+
+    int start() {
+        if (!host) return WOL_OK;
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        const int Fmax = std::min(Fb, T_frames);
+        for (int k = 0; k < 2; ++k) {
+            if (!c->copied_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->copied_ev[k], hipEventDisableTiming));
+            if (!c->consumed_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->consumed_ev[k], hipEventDisableTiming));
+            if (k < nbatch) {
+                WOL_TRY(c->host_stage[k].ensure(pack ? (size_t)Fmax * n * 3 * sizeof(T) : batch_elems(Fmax) * sizeof(T)));
+                if (pack) WOL_TRY(c->pack_stage[k].ensure((size_t)Fmax * n * 3 * sizeof(T)));
+            }
+        }
+        // earlier work on the context's stream may still read the staging sets (a previous call's last batches)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        c->last_h2d_bytes = 0.0;
+        return enqueue_copy(0);
+    }
+
+    // batch b as a device view; its kernels may be enqueued on c->stream right away
+    int acquire(int b, FrameBatchView* v) {
+        const int f0 = bstart[b];
+        if (host) {
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->copied_ev[b & 1], 0));
+            v->base = c->host_stage[b & 1].p;
+            v->f32 = batch_f32[b & 1];
+            if (pack) { v->atom_stride = 3; v->frame_stride = 3 * (int64_t)n; }
+            else { v->atom_stride = atom_stride; v->frame_stride = frame_stride; }
+        } else {
+            v->base = frames + (int64_t)f0 * frame_stride;
+            v->f32 = !std::is_same<T, double>::value;
+            v->atom_stride = atom_stride; v->frame_stride = frame_stride;
+        }
+        return WOL_OK;
+    }
+
+    // batch b's kernels are enqueued: its staging set may be refilled behind them, the next batch may start to travel
+    int release(int b) {
+        if (!host) return WOL_OK;
+        HIP_TRY(hipEventRecord(c->consumed_ev[b & 1], c->stream));
+        // (a copy from pageable memory, or the packing, blocks the host: this batch's kernels are enqueued already)
+        if (b + 1 < nbatch) WOL_TRY(enqueue_copy(b + 1));
+        return WOL_OK;
+    }
+};
+
+// populations of a trajectory call (tetOrderCalc / threeBodyCalc / lsiCalc with subInds): query points by position
+struct PopQuery {
+    const void* pos = nullptr;       // [total][3] reals of the call's dtype, in the call's memory space
+    const int64_t* off = nullptr;    // host [T * npops + 1]
+    int npops = 0;
+};
+
+// stages the population points (as doubles) and their offsets on the device; *total = number of points
+int stage_populations(wol_ctx* c, const PopQuery& pq, int T_frames, int dtype, int mem, const double** d_pts, const long long** d_off, int64_t* total) {
+    *d_pts = nullptr; *d_off = nullptr; *total = 0;
+    if (pq.npops <= 0) return WOL_OK;
+    if (!pq.off) return fail(WOL_ERR_INVALID, "population offsets must not be NULL");
+    const size_t noff = (size_t)T_frames * pq.npops + 1;
+    if (pq.off[0] != 0) return fail(WOL_ERR_INVALID, "population offsets must start at 0");
+    for (size_t i = 1; i < noff; ++i)
+        if (pq.off[i] < pq.off[i - 1]) return fail(WOL_ERR_INVALID, "population offsets must not decrease");
+    *total = pq.off[noff - 1];
+    if (*total > 0 && !pq.pos) return fail(WOL_ERR_INVALID, "population points must not be NULL");
+    WOL_TRY(c->pop_off.ensure(sizeof(long long) * noff));
+    HIP_TRY(hipMemcpyAsync(c->pop_off.p, pq.off, sizeof(long long) * noff, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));    // (the caller's offsets array may be a temporary)
+    *d_off = c->pop_off.as<long long>();
+    if (*total > 0) {
+        if (dtype == WOL_F64 && mem == WOL_MEM_DEVICE) {
+            *d_pts = static_cast<const double*>(pq.pos);
+        } else {
+            WOL_TRY(c->pop_pts.ensure(sizeof(double) * 3 * (size_t)*total));
+            WOL_TRY(fetch_f64(c, RealSrc{pq.pos, dtype, mem}, 3 * (size_t)*total, c->pop_pts.as<double>()));
+            *d_pts = c->pop_pts.as<double>();
+        }
+    }
+    return WOL_OK;
+}
+
+template <typename U>
+FramesView<U> view_as(const FrameBatchView& v, int n) {
+    FramesView<U> fv;
+    fv.base = static_cast<const U*>(v.base);
+    fv.atom_stride = v.atom_stride;
+    fv.frame_stride = v.frame_stride;
+    fv.n = n;
+    return fv;
+}
+
 template <typename T>
 int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_stride, int T_frames,
                 int n, const double* boxes, double low, double high, double* mean, double* var,
-                int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, T* q_out, int mem) {
+                int64_t* qhist, int qbins, int64_t* dhist, int dbins, double dbinwidth, T* q_out, int mem,
+                const PopQuery* pq = nullptr, double* pop_mean = nullptr, double* pop_var = nullptr, int64_t* pop_qhist = nullptr,
+                T* pop_q = nullptr) {
     WOL_TRY(check_ctx(c));
     if (!frames || !boxes) return fail(WOL_ERR_INVALID, "frames/boxes must not be NULL");
     if (T_frames < 0 || n <= 0) return fail(WOL_ERR_INVALID, "need T >= 0 and n > 0 (got T=%d n=%d)", T_frames, n);
@@ -1081,27 +1318,31 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
     if (dhist && (dbins <= 0 || !(dbinwidth > 0.0))) return fail(WOL_ERR_INVALID, "dbins/dbinwidth must be > 0");
     if ((qhist ? qbins : 0) + (dhist ? dbins : 0) > 12000) return fail(WOL_ERR_INVALID, "too many histogram bins for LDS");
     if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    const int npops = pq ? pq->npops : 0;
+    if (npops < 0) return fail(WOL_ERR_INVALID, "npops must be >= 0");
+    if (npops > 0 && pop_qhist && qbins <= 0) return fail(WOL_ERR_INVALID, "qbins must be > 0");
     if (T_frames == 0) return WOL_OK;
     const bool host = (mem == WOL_MEM_HOST);
+    const int dtype = std::is_same<T, double>::value ? WOL_F64 : WOL_F32;
 
-    int Fb = c->frames_per_batch;
-    if (Fb <= 0) {
-        if (host) {
-            // host frames: batches of ~256 MB (at least 64 frames: the streaming sort wants that many), so the first
-            // copy -- the only one no kernel runs under -- stays a small part of the job
-            const double frame_bytes = (double)frame_stride * sizeof(T);
-            Fb = (int)std::fmin(4096.0, std::fmax(64.0, 256.0e6 / frame_bytes));
-            const double per_frame = (double)n * 64.0 + 2.0 * frame_bytes;
-            Fb = (int)std::fmin((double)Fb, std::fmax(1.0, 6.0e9 / per_frame));
-        } else {
-            // device-resident frames: up to 125 M waters per batch (about 30 GB of intermediate arrays in three sets, of
-            // 288 GB) -- a 32-frame block of a million-water box is one batch, not 24 + 8
-            const double per_frame = (double)n * 64.0;
-            Fb = (int)std::fmin((double)T_frames, std::fmax(1.0, 8.0e9 / per_frame));
-        }
-        if (Fb >= 8 && Fb < T_frames) Fb = (Fb / 8) * 8;
+    FrameFeeder<T> feed;
+    WOL_TRY(feed.plan(c, frames, atom_stride, frame_stride, T_frames, n, host, 64.0));
+    const int Fb = feed.Fb, nbatch = feed.nbatch;
+
+    // populations: points and offsets on the device, integer accumulators per (frame, population) segment
+    const double* d_pts = nullptr;
+    const long long* d_poff = nullptr;
+    int64_t npts = 0;
+    const int npops1 = npops + 1;
+    if (npops > 0) {
+        WOL_TRY(stage_populations(c, *pq, T_frames, dtype, mem, &d_pts, &d_poff, &npts));
+        const size_t sb = sizeof(unsigned long long) * 8 * (size_t)T_frames * npops1, hb = sizeof(unsigned long long) * (size_t)npops * std::max(qbins, 1);
+        WOL_TRY(c->pop_stat.ensure(sb));
+        WOL_TRY(c->pop_hist.ensure(hb));
+        HIP_TRY(hipMemsetAsync(c->pop_stat.p, 0, sb, c->stream));
+        HIP_TRY(hipMemsetAsync(c->pop_hist.p, 0, hb, c->stream));
+        if (pop_q && npts > 0) WOL_TRY(c->pop_out.ensure(sizeof(double) * (size_t)npts));
     }
-    Fb = std::min(Fb, T_frames);
 
     // device histograms (uint64 == the caller's int64 bit pattern for non-negative counts)
     unsigned long long* d_qh = nullptr;
@@ -1122,44 +1363,7 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         WOL_TRY(c->small.ensure(sizeof(double) * 2 * (size_t)T_frames));
         d_stats = c->small.as<double>();
     }
-
-    // ---- host frames: double-buffered staging.  The link carries the frames as they lie in host memory (whole
-    // interleaved frames: measured on MI355X, a strided copy of the 24-byte O rows -- hipMemcpy2DAsync or a gather
-    // kernel over mapped host memory -- is no faster than the linear copy of everything, tools/pcie_probe.hip), the
-    // kernels pick the O rows out of the staged frames through the atom stride.
-    // batch b = frames [bstart[b], bstart[b + 1]).  Host frames: what the call costs beyond the copies is the kernels of the
-    // LAST batch (nothing crosses the link under them), so the tail of a several-batch call is cut off as a batch of its own
-    // of at most 32 frames
-    std::vector<int> bstart;
-    for (int f0 = 0; f0 < T_frames; f0 += Fb) bstart.push_back(f0);
-    bstart.push_back(T_frames);
-    if (host && c->frames_per_batch <= 0 && bstart.size() >= 3) {
-        const int last = T_frames - bstart[bstart.size() - 2];
-        if (last > 48) bstart.insert(bstart.end() - 1, T_frames - 32);
-    }
-    const int nbatch = (int)bstart.size() - 1;
-    auto batch_elems = [&](int F) { return (size_t)(F - 1) * frame_stride + (size_t)(n - 1) * atom_stride + 3; };
-    auto enqueue_copy = [&](int b) -> int {
-        const int f0 = bstart[b], F = bstart[b + 1] - f0, k = b & 1;
-        if (b >= 2) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->consumed_ev[k], 0));   // batch b-2 is done with this set
-        HIP_TRY(hipMemcpyAsync(c->host_stage[k].p, frames + (int64_t)f0 * frame_stride, batch_elems(F) * sizeof(T),
-                               hipMemcpyHostToDevice, c->copy_stream));
-        HIP_TRY(hipEventRecord(c->copied_ev[k], c->copy_stream));
-        c->last_h2d_bytes += (double)(batch_elems(F) * sizeof(T));
-        return WOL_OK;
-    };
-    if (host) {
-        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < 2; ++k) {
-            if (!c->copied_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->copied_ev[k], hipEventDisableTiming));
-            if (!c->consumed_ev[k]) HIP_TRY(hipEventCreateWithFlags(&c->consumed_ev[k], hipEventDisableTiming));
-            if (k < nbatch) WOL_TRY(c->host_stage[k].ensure(batch_elems(std::min(Fb, T_frames)) * sizeof(T)));
-        }
-        // earlier work on the context's stream may still read the staging sets (a previous call's last batches)
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->last_h2d_bytes = 0.0;
-        WOL_TRY(enqueue_copy(0));
-    }
+    WOL_TRY(feed.start());
 
     if (c->overlap && !host && !c->inputs_resident) {
         // overlapped batches sort on a side stream: mark, once per call and whether or not the first batch is piped, the
@@ -1168,18 +1372,10 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         HIP_TRY(hipEventRecord(c->in_ev, c->stream));
     }
     for (int b = 0; b < nbatch; ++b) {
-        const int f0 = bstart[b];
-        const int F = bstart[b + 1] - f0;
-        FramesView<T> fv;
-        fv.atom_stride = atom_stride;
-        fv.frame_stride = frame_stride;
-        fv.n = n;
-        if (host) {
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->copied_ev[b & 1], 0));
-            fv.base = c->host_stage[b & 1].as<T>();
-        } else {
-            fv.base = frames + (int64_t)f0 * frame_stride;
-        }
+        const int f0 = feed.bstart[b];
+        const int F = feed.bstart[b + 1] - f0;
+        FrameBatchView bv;
+        WOL_TRY(feed.acquire(b, &bv));
         QOut out;
         memset(&out, 0, sizeof out);
         double* qd = nullptr;
@@ -1207,7 +1403,10 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
             HIP_TRY(hipMemsetAsync(c->stat.p, 0, sizeof(unsigned long long) * 4 * (size_t)F, c->stream));
             out.stat = c->stat.as<unsigned long long>();
         }
-        WOL_TRY(run_q_batch<T>(c, fv, F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, host ? 0 : (b == 0 ? 1 : 2)));
+        const int pipe_mode = host ? 0 : (b == 0 ? 1 : 2);
+        // (a packed batch narrowed to float32 runs the float instantiation: exact promotion, identical results)
+        if (bv.f32) WOL_TRY(run_q_batch<float>(c, view_as<float>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0));
+        else WOL_TRY(run_q_batch<double>(c, view_as<double>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0));
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
             double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
@@ -1215,18 +1414,47 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
                                c->stat.as<unsigned long long>(), c->stat_slots ? c->stat_part.as<long long>() : nullptr,
                                c->stat_slots, F, n, dm, dv);
         }
-        if (host) {
-            HIP_TRY(hipEventRecord(c->consumed_ev[b & 1], c->stream));
-            // the next batch's frames cross the link while this batch's kernels run (a copy from pageable memory
-            // blocks the host until it is staged: this batch's kernels are enqueued already)
-            if (b + 1 < nbatch) WOL_TRY(enqueue_copy(b + 1));
-            if (q_out) {   // behind this batch's kernels on the stream; the staging buffer is reused in stream order
-                if (std::is_same<T, double>::value)
-                    HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, qd, sizeof(double) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
-                else
-                    HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, q32d, sizeof(float) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
-            }
+        if (npops > 0 && feed.bstart[b + 1] > f0 && pq->off[(size_t)(f0 + F) * npops] > pq->off[(size_t)f0 * npops] && c->last_set) {
+            // the populations' points of these frames against the batch just sorted (its arrays stay valid until the
+            // set is reused, behind this stream)
+            wol_ctx::SortSet& S = *c->last_set;
+            TrajShellArgs ta;
+            memset(&ta, 0, sizeof ta);
+            ta.grids = S.grids.as<FrameGrid>(); ta.sorted = S.sorted.as<double4>(); ta.cell_start = S.cells.as<int>();
+            ta.n = n; ta.F = F; ta.f0 = f0; ta.npops = npops;
+            ta.lowsq = low * low; ta.highsq = high * high;
+            ta.pts = d_pts; ta.pt_off = d_poff;
+            ta.hist = c->pop_hist.as<unsigned long long>(); ta.stat = c->pop_stat.as<unsigned long long>();
+            const int64_t pts_here = pq->off[(size_t)(f0 + F) * npops] - pq->off[(size_t)f0 * npops];
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((pts_here + 3) / 4, 8 * (int64_t)c->num_cus));
+            hipLaunchKernelGGL(k_q_traj_points, dim3(grid), dim3(WOL_BLOCK), 0, c->stream, ta, high, qbins,
+                               (pop_q && npts > 0) ? c->pop_out.as<double>() : nullptr);
         }
+        WOL_TRY(feed.release(b));
+        if (host && q_out) {   // behind this batch's kernels on the stream; the staging buffer is reused in stream order
+            if (std::is_same<T, double>::value)
+                HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, qd, sizeof(double) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+            else
+                HIP_TRY(hipMemcpyAsync(q_out + (int64_t)f0 * n, q32d, sizeof(float) * (size_t)F * n, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    if (npops > 0) {
+        // per (frame, population): np.mean / np.var of the population's q (NaN for an empty one, as numpy); histograms
+        // ACCUMULATE into the caller's [npops][qbins] array like the all-waters histogram
+        const int nseg = T_frames * npops1;
+        WOL_TRY(c->pop_res.ensure(sizeof(double) * 2 * (size_t)T_frames * npops));
+        double* rm = c->pop_res.as<double>();
+        double* rv = rm + (size_t)T_frames * npops;
+        hipLaunchKernelGGL(k_traj_finalize, dim3((nseg + 255) / 256), dim3(256), 0, c->stream, c->pop_stat.as<unsigned long long>(), nseg, 0,
+                           npops1, 1, 1, (long long*)nullptr, rm, rv);
+        const size_t nb = sizeof(double) * (size_t)T_frames * npops;
+        const hipMemcpyKind kind = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+        if (pop_mean) HIP_TRY(hipMemcpyAsync(pop_mean, rm, nb, kind, c->stream));
+        if (pop_var) HIP_TRY(hipMemcpyAsync(pop_var, rv, nb, kind, c->stream));
+        if (pop_q && npts > 0) WOL_TRY(deliver_f64(c, c->pop_out.as<double>(), pop_q, (size_t)npts, dtype, mem, 3));
+        if (pop_qhist && !host)
+            hipLaunchKernelGGL(k_add_u64, dim3((npops * qbins + 255) / 256), dim3(256), 0, c->stream, c->pop_hist.as<unsigned long long>(),
+                               reinterpret_cast<unsigned long long*>(pop_qhist), npops * qbins);
     }
     if (host) {
         if (mean) HIP_TRY(hipMemcpyAsync(mean, d_stats, sizeof(double) * (size_t)T_frames, hipMemcpyDeviceToHost, c->stream));
@@ -1238,8 +1466,187 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
             if (qhist) for (int k = 0; k < qbins; ++k) qhist[k] += (int64_t)h[k];
             if (dhist) for (int k = 0; k < dbins; ++k) dhist[k] += (int64_t)h[(size_t)qbins + k];
         }
+        if (npops > 0 && pop_qhist) {
+            std::vector<unsigned long long> h((size_t)npops * qbins);
+            HIP_TRY(hipMemcpy(h.data(), c->pop_hist.p, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < h.size(); ++k) pop_qhist[k] += (int64_t)h[k];
+        }
     }
     HIP_TRY(hipGetLastError());
+    return WOL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// threeBodyCalc / lsiCalc frame loops (wol_cos_angs_traj, wol_lsi_traj): batches through the feeder and the sort stage,
+// the kernels of wol_shell_traj.hip, integer accumulators per (frame, population) segment on the device.
+// ---------------------------------------------------------------------------------------------
+struct ShellTrajOut {
+    int kind = 0;                 // 0 = three-body angles, 1 = LSI
+    int nbins = 0;
+    double hist_max = 0.0;
+    int64_t* hist = nullptr;      // kind 0: [T][npops + 1][nbins] written; kind 1: [npops + 1][nbins] accumulated
+    int64_t* counts = nullptr;    // kind 0: [T][npops + 1][2]; kind 1: [T][npops + 1]
+    double* a = nullptr;          // kind 0: cos sums [T][npops + 1][2]; kind 1: mean [T][npops + 1]
+    double* b = nullptr;          // kind 1: var
+    void* per_water = nullptr;    // kind 1: [T][n] reals of the call's dtype or null
+    void* per_point = nullptr;    // kind 1: [total points] or null
+};
+
+template <typename T>
+int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_stride, int T_frames, int n, const double* boxes,
+                    double low, double high, const PopQuery& pq, const ShellTrajOut& o, int mem) {
+    WOL_TRY(check_ctx(c));
+    if (!frames || !boxes) return fail(WOL_ERR_INVALID, "frames/boxes must not be NULL");
+    if (T_frames < 0 || n <= 0) return fail(WOL_ERR_INVALID, "need T >= 0 and n > 0 (got T=%d n=%d)", T_frames, n);
+    if (atom_stride < 3) return fail(WOL_ERR_INVALID, "atom_stride must be >= 3");
+    if (frame_stride < (int64_t)(n - 1) * atom_stride + 3 && T_frames > 1) return fail(WOL_ERR_INVALID, "frame_stride smaller than one frame");
+    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    if (o.nbins <= 0 || o.nbins > 16000) return fail(WOL_ERR_INVALID, "need 0 < nbins <= 16000");
+    if (o.kind == 1 && !(o.hist_max > 0.0)) return fail(WOL_ERR_INVALID, "histogram range must be positive");
+    if (!(high > 0.0) || !(low >= 0.0)) return fail(WOL_ERR_INVALID, "need lowcut >= 0 and highcut > 0");
+    const int npops = pq.npops;
+    if (npops < 0) return fail(WOL_ERR_INVALID, "npops must be >= 0");
+    if (T_frames == 0) return WOL_OK;
+    const bool host = (mem == WOL_MEM_HOST);
+    const int dtype = std::is_same<T, double>::value ? WOL_F64 : WOL_F32;
+    const int npops1 = npops + 1, nseg = T_frames * npops1;
+
+    FrameFeeder<T> feed;
+    WOL_TRY(feed.plan(c, frames, atom_stride, frame_stride, T_frames, n, host, 96.0));
+    const int nbatch = feed.nbatch;
+    const double* d_pts = nullptr;
+    const long long* d_poff = nullptr;
+    int64_t npts = 0;
+    WOL_TRY(stage_populations(c, pq, T_frames, dtype, mem, &d_pts, &d_poff, &npts));
+
+    const size_t stat_b = sizeof(unsigned long long) * 8 * (size_t)nseg;
+    const size_t hist_n = (o.kind == 0 ? (size_t)nseg : (size_t)npops1) * o.nbins;
+    WOL_TRY(c->pop_stat.ensure(stat_b));
+    WOL_TRY(c->pop_hist.ensure(sizeof(unsigned long long) * hist_n));
+    HIP_TRY(hipMemsetAsync(c->pop_stat.p, 0, stat_b, c->stream));
+    HIP_TRY(hipMemsetAsync(c->pop_hist.p, 0, sizeof(unsigned long long) * hist_n, c->stream));
+    // waters whose shell outgrows the kernels' LDS rows are listed and finished by the slow kernels: the three-body one
+    // recomputes (no storage: every water may be listed), the LSI one keeps rows of WOL_TRAJ_LSI_SLOWROW doubles in global memory
+    const int64_t batch_waters = (int64_t)feed.Fb * n;
+    const int slow_cap = o.kind == 0 ? (int)std::min<int64_t>(batch_waters, 1 << 30)
+                                     : (int)std::min<int64_t>(std::max<int64_t>(4096, batch_waters / 16), 32768);
+    WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)slow_cap));
+    WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
+    HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
+    if (o.kind == 1) WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)slow_cap * WOL_TRAJ_LSI_SLOWROW));
+    if (o.per_point && npts > 0) WOL_TRY(c->pop_out.ensure(sizeof(double) * (size_t)npts));
+    const bool pw_direct = o.per_water && !host && dtype == WOL_F64;
+    // cells as wide as the reach (27-cell walk) for short reaches, half the reach (125 cells) for long ones
+    const double reach = o.kind == 0 ? high : high + 3.7;     // water_properties.py:276, 281
+    const double cell_w = reach < 5.0 ? reach * 1.001 : std::fmax(reach * 0.5, 2.5);
+    // LSI: LDS rows for twice the shell the first frame's mean density predicts (+ the next neighbour + head-room)
+    int lsi_row = WOL_TRAJ_LSI_ROW;
+    if (o.kind == 1 && boxes[0] > 0.0 && boxes[1] > 0.0 && boxes[2] > 0.0) {
+        const double rho = (double)n / (boxes[0] * boxes[1] * boxes[2]);
+        const double kexp = rho * (4.0 / 3.0) * WOL_PI * (high * high * high - low * low * low);
+        lsi_row = (int)std::fmin((double)WOL_TRAJ_LSI_ROWMAX, std::fmax((double)WOL_TRAJ_LSI_ROW, 2.0 * kexp + 8.0));
+    }
+    bool lsi_lds_set = false;
+    WOL_TRY(feed.start());
+    for (int b = 0; b < nbatch; ++b) {
+        const int f0 = feed.bstart[b], F = feed.bstart[b + 1] - f0;
+        FrameBatchView bv;
+        WOL_TRY(feed.acquire(b, &bv));
+        BatchPlan bp;
+        if (bv.f32) WOL_TRY(sort_batch<float>(c, view_as<float>(bv, n), F, boxes + 3 * (size_t)f0, cell_w, reach, false, false, 0, &bp, true));
+        else WOL_TRY(sort_batch<double>(c, view_as<double>(bv, n), F, boxes + 3 * (size_t)f0, cell_w, reach, false, false, 0, &bp, true));
+        wol_ctx::SortSet& S = *bp.S;
+        TrajShellArgs ta;
+        memset(&ta, 0, sizeof ta);
+        ta.grids = S.grids.as<FrameGrid>(); ta.sorted = S.sorted.as<double4>(); ta.cell_start = S.cells.as<int>();
+        ta.n = n; ta.F = F; ta.f0 = f0; ta.npops = npops;
+        ta.lowsq = low * low; ta.highsq = high * high;
+        ta.pts = d_pts; ta.pt_off = d_poff;
+        ta.nbins = o.nbins; ta.hist_max = o.hist_max;
+        ta.hist = c->pop_hist.as<unsigned long long>(); ta.stat = c->pop_stat.as<unsigned long long>();
+        ta.slow_list = c->slow_list.as<unsigned long long>();
+        ta.slow_count = c->slow_count.as<int>(); ta.error_flag = c->slow_count.as<int>() + 1; ta.slow_cap = slow_cap;
+        HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int), c->stream));   // (the error flag stays up)
+        double* pw_stage = nullptr;
+        if (o.per_water) {
+            if (pw_direct) ta.per_water = static_cast<double*>(o.per_water);
+            else {
+                WOL_TRY(c->out_stage.ensure(sizeof(double) * (size_t)feed.Fb * n));
+                pw_stage = c->out_stage.as<double>();
+                ta.per_water = pw_stage - (int64_t)f0 * n;    // (indexed by the frame's number in the call)
+            }
+        }
+        const int64_t pts_here = npops > 0 ? pq.off[(size_t)(f0 + F) * npops] - pq.off[(size_t)f0 * npops] : 0;
+        const size_t lds = sizeof(int) * (size_t)o.nbins;
+        const int64_t need = (int64_t)F * ((n + WOL_TRAJ_BLOCK - 1) / WOL_TRAJ_BLOCK);
+        int grid = 0;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+        if (o.kind == 0) {
+            WOL_TRY(resident_grid(c, k_cos_angs_traj, WOL_TRAJ_BLOCK, lds, need, &grid));
+            hipLaunchKernelGGL(k_cos_angs_traj, dim3(grid), dim3(WOL_TRAJ_BLOCK), lds, c->stream, ta);
+            if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+            hipLaunchKernelGGL(k_cos_angs_traj_slow, dim3(16), dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta);
+            if (pts_here > 0)
+                hipLaunchKernelGGL(k_cos_angs_traj_points, dim3((unsigned)std::min<int64_t>((pts_here + WOL_TRAJ_BLOCK - 1) / WOL_TRAJ_BLOCK, 4096)),
+                                   dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta);
+        } else {
+            const double high2 = high + 3.7;
+            const size_t rows_lds = sizeof(double) * (size_t)lsi_row * WOL_TRAJ_BLOCK;
+            if (!lsi_lds_set && rows_lds + lds > 48 * 1024) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsi_traj), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsi_traj_points), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+                lsi_lds_set = true;
+            }
+            WOL_TRY(resident_grid(c, k_lsi_traj, WOL_TRAJ_BLOCK, rows_lds + lds, need, &grid));
+            hipLaunchKernelGGL(k_lsi_traj, dim3(grid), dim3(WOL_TRAJ_BLOCK), rows_lds + lds, c->stream, ta, high2 * high2, lsi_row);
+            if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+            double* ptq = (o.per_point && npts > 0) ? c->pop_out.as<double>() : nullptr;
+            if (pts_here > 0)
+                hipLaunchKernelGGL(k_lsi_traj_points, dim3((unsigned)std::min<int64_t>((pts_here + WOL_TRAJ_BLOCK - 1) / WOL_TRAJ_BLOCK, 4096)),
+                                   dim3(WOL_TRAJ_BLOCK), rows_lds, c->stream, ta, high2 * high2, lsi_row, ptq);
+            hipLaunchKernelGGL(k_lsi_traj_slow, dim3(16), dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta, high2 * high2, c->qbuf.as<double>(), ptq);
+        }
+        HIP_TRY(hipEventRecord(S.free_ev, c->stream));
+        S.used = true;
+        if (pw_stage)
+            WOL_TRY(deliver_f64(c, pw_stage, static_cast<char*>(o.per_water) + (size_t)f0 * n * (dtype == WOL_F64 ? sizeof(double) : sizeof(float)),
+                                (size_t)F * n, dtype, mem, 0));
+        WOL_TRY(feed.release(b));
+    }
+    // ---- per-segment results from the integer accumulators ----
+    const hipMemcpyKind back = host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const size_t per_seg = o.kind == 0 ? 2 : 1;
+    WOL_TRY(c->pop_res.ensure((sizeof(long long) + 2 * sizeof(double)) * per_seg * (size_t)nseg + 64));
+    long long* r_cnt = c->pop_res.as<long long>();
+    double* r_a = reinterpret_cast<double*>(r_cnt + per_seg * (size_t)nseg);
+    double* r_b = r_a + per_seg * (size_t)nseg;
+    hipLaunchKernelGGL(k_traj_finalize, dim3((nseg + 255) / 256), dim3(256), 0, c->stream, c->pop_stat.as<unsigned long long>(), nseg, 0,
+                       npops1, o.kind, 0, r_cnt, r_a, r_b);
+    if (o.counts) HIP_TRY(hipMemcpyAsync(o.counts, r_cnt, sizeof(long long) * per_seg * (size_t)nseg, back, c->stream));
+    if (o.a) HIP_TRY(hipMemcpyAsync(o.a, r_a, sizeof(double) * per_seg * (size_t)nseg, back, c->stream));
+    if (o.kind == 1 && o.b) HIP_TRY(hipMemcpyAsync(o.b, r_b, sizeof(double) * (size_t)nseg, back, c->stream));
+    if (o.per_point && npts > 0) WOL_TRY(deliver_f64(c, c->pop_out.as<double>(), o.per_point, (size_t)npts, dtype, mem, 3));
+    if (o.hist) {
+        if (o.kind == 0) {
+            HIP_TRY(hipMemcpyAsync(o.hist, c->pop_hist.p, sizeof(long long) * hist_n, back, c->stream));
+        } else if (!host) {
+            hipLaunchKernelGGL(k_add_u64, dim3((unsigned)((hist_n + 255) / 256)), dim3(256), 0, c->stream, c->pop_hist.as<unsigned long long>(),
+                               reinterpret_cast<unsigned long long*>(o.hist), (int)hist_n);
+        }
+    }
+    // the shell kernels report a shell too dense for their rows through a flag: one synchronisation per call
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, c->slow_count.p, sizeof flags, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (o.hist && o.kind == 1 && host) {
+        std::vector<unsigned long long> h(hist_n);
+        HIP_TRY(hipMemcpy(h.data(), c->pop_hist.p, sizeof(unsigned long long) * hist_n, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < hist_n; ++k) o.hist[k] += (int64_t)h[k];
+    }
+    HIP_TRY(hipGetLastError());
+    if (flags[1] == 1) return fail(WOL_ERR_INVALID, "more than %d waters of a batch have shells denser than the trajectory form's rows (%d); use the per-frame call", slow_cap, lsi_row - 2);
+    if (flags[1] == 2) return fail(WOL_ERR_INVALID, "a shell holds more than %d waters; use the per-frame call", WOL_TRAJ_LSI_SLOWROW - 2);
     return WOL_OK;
 }
 
@@ -1300,9 +1707,11 @@ int wol_ctx_destroy(wol_ctx* c) {
     if (c->grid_stream) { (void)hipStreamSynchronize(c->grid_stream); (void)hipStreamDestroy(c->grid_stream); }
     for (DevBuf* b : bufs) b->release();
     c->cvt_in.release(); c->xchg.release(); c->stat_part.release(); c->prop_counters.release();
+    c->pop_off.release(); c->pop_pts.release(); c->pop_stat.release(); c->pop_hist.release(); c->pop_out.release(); c->pop_res.release();
     for (auto& b : c->cvt_out) b.release();
     for (int k = 0; k < 2; ++k) {
         c->host_stage[k].release();
+        c->pack_stage[k].release();
         if (c->copied_ev[k]) (void)hipEventDestroy(c->copied_ev[k]);
         if (c->consumed_ev[k]) (void)hipEventDestroy(c->consumed_ev[k]);
     }
@@ -1368,6 +1777,12 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->search_margin = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0.0;
+    } else if (k == "host_pack") {
+        if (value != 0.0 && value != 1.0 && value != 2.0) return fail(WOL_ERR_INVALID, "host_pack must be 0, 1 or 2");
+        c->host_pack = (int)value;
+    } else if (k == "host_threads") {
+        if (!(value >= 0 && value <= 256)) return fail(WOL_ERR_INVALID, "host_threads must be 0..256");
+        c->host_threads = (int)value;
     } else if (k == "check_proposals") {
         // (re)starts the counters "proposals_written" / "proposals_expected" / "proposals_bad"
         WOL_TRY(check_ctx(c));
@@ -2018,6 +2433,49 @@ int wol_q_traj_f32(wol_ctx* c, const float* frames, int64_t atom_stride, int64_t
                    int qbins, int64_t* dhist, int dbins, double dbinwidth, float* q_out, int mem) {
     return q_traj_impl<float>(c, frames, atom_stride, frame_stride, T, n, boxes, lowcut, highcut, mean, var,
                               qhist, qbins, dhist, dbins, dbinwidth, q_out, mem);
+}
+
+int wol_q_traj_pops(wol_ctx* c, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n, const double* boxes,
+                    double lowcut, double highcut, double* mean, double* var, int64_t* qhist, int qbins, int64_t* dhist, int dbins,
+                    double dbinwidth, void* q_out, const void* pop_pos, const int64_t* pop_off, int npops, double* pop_mean,
+                    double* pop_var, int64_t* pop_qhist, void* pop_q, int dtype, int mem) {
+    WOL_TRY(check_real(dtype, mem));
+    PopQuery pq;
+    pq.pos = pop_pos; pq.off = pop_off; pq.npops = npops;
+    if (dtype == WOL_F64)
+        return q_traj_impl<double>(c, static_cast<const double*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, mean, var,
+                                   qhist, qbins, dhist, dbins, dbinwidth, static_cast<double*>(q_out), mem, &pq, pop_mean, pop_var, pop_qhist,
+                                   static_cast<double*>(pop_q));
+    return q_traj_impl<float>(c, static_cast<const float*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, mean, var,
+                              qhist, qbins, dhist, dbins, dbinwidth, static_cast<float*>(q_out), mem, &pq, pop_mean, pop_var, pop_qhist,
+                              static_cast<float*>(pop_q));
+}
+
+int wol_cos_angs_traj(wol_ctx* c, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n, const double* boxes,
+                      double lowcut, double highcut, const void* pop_pos, const int64_t* pop_off, int npops, int nbins,
+                      int64_t* ang_hist, int64_t* counts, double* cos_sums, int dtype, int mem) {
+    WOL_TRY(check_real(dtype, mem));
+    PopQuery pq;
+    pq.pos = pop_pos; pq.off = pop_off; pq.npops = npops;
+    ShellTrajOut o;
+    o.kind = 0; o.nbins = nbins; o.hist = ang_hist; o.counts = counts; o.a = cos_sums;
+    if (dtype == WOL_F64)
+        return shell_traj_impl<double>(c, static_cast<const double*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, pq, o, mem);
+    return shell_traj_impl<float>(c, static_cast<const float*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, pq, o, mem);
+}
+
+int wol_lsi_traj(wol_ctx* c, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n, const double* boxes,
+                 double lowcut, double highcut, const void* pop_pos, const int64_t* pop_off, int npops, int nbins, double hist_max,
+                 int64_t* lsi_hist, int64_t* counts, double* mean, double* var, void* lsi_out, void* pop_lsi, int dtype, int mem) {
+    WOL_TRY(check_real(dtype, mem));
+    PopQuery pq;
+    pq.pos = pop_pos; pq.off = pop_off; pq.npops = npops;
+    ShellTrajOut o;
+    o.kind = 1; o.nbins = nbins; o.hist_max = hist_max; o.hist = lsi_hist; o.counts = counts; o.a = mean; o.b = var;
+    o.per_water = lsi_out; o.per_point = pop_lsi;
+    if (dtype == WOL_F64)
+        return shell_traj_impl<double>(c, static_cast<const double*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, pq, o, mem);
+    return shell_traj_impl<float>(c, static_cast<const float*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, pq, o, mem);
 }
 
 }  // extern "C"

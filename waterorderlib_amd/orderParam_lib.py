@@ -8,9 +8,9 @@ with ``.traj`` and ``getWatInds()``: the array-backed waterorderlib_amd.TrajObje
 reference's own pytraj-backed class) instead of a path; paths need parmed/pytraj, which the
 reference imports at TrajObject.py:10-11 and which are outside this build.
 
-The frame loop itself moves to the GPU: the trajectory is read lazily in chunks, every chunk is one wol_q_traj call
-(frames batched in HBM, the copy of one batch under the kernels of the previous, nothing per-water on the host);
-sub-populations use wol_q_frame per frame.
+The frame loops themselves move to the GPU: the trajectory is read lazily in chunks, every chunk is one call of
+wol_q_traj(_pops) / wol_cos_angs_traj / wol_lsi_traj (frames batched in HBM, the copy of one batch under the kernels of
+the previous, nothing per-water on the host); sub-populations ride along as position lists.
 """
 import numpy as np
 
@@ -106,20 +106,18 @@ def tetOrderCalc(topFile, trajFile=None, subInds=None, nPops=0, solResName='(!:W
         select = span if regular else watInds
     for t0, xyz, boxes in (_frame_chunks(traj, select, chunk_bytes) if nW else ()):
         if nPops:
+            # one call per chunk: q of all waters and of every population's points (pos[subInds[t][j]], opl:1466) against
+            # the frame's waters -- wol_q_traj_pops sorts every frame once for both
             waters = np.ascontiguousarray(xyz[:, span] if regular else xyz[:, watInds])
+            pop_pos, pop_off = engine.pack_populations(xyz, [subInds[t0 + k] for k in range(len(xyz))], nPops)
+            res = engine.tet_order_traj_pops(waters, boxes, pop_pos, pop_off, nPops, len_wat=lenWat if regular else 1)
+            for j in range(1, nPops + 1):
+                avgQ[j].extend(res.pop_mean[:, j - 1]); varQ[j].extend(res.pop_var[:, j - 1])
+                qHist[j] += res.pop_qhist[j - 1]
         else:
-            waters = xyz
-        res = engine.tet_order_traj(waters, boxes, len_wat=lenWat if regular else 1, want_dhist=False)
+            res = engine.tet_order_traj(xyz, boxes, len_wat=lenWat if regular else 1, want_dhist=False)
         avgQ[0].extend(res.mean); varQ[0].extend(res.var)
         qHist[0] += res.qhist
-        for k in range(len(xyz) if nPops else 0):
-            t = t0 + k
-            watPos = np.ascontiguousarray(xyz[k][watInds], dtype=np.float64)
-            for j in range(1, nPops + 1):
-                subPos = np.asarray(xyz[k], dtype=np.float64)[subInds[t][j - 1]]
-                jQ = wp.getOrderParamq(subPos, watPos, boxes[k])
-                avgQ[j].append(np.mean(jQ)); varQ[j].append(np.var(jQ))
-                qHist[j] += np.histogram(jQ, bins=engine.QBINS, range=[0.0, 1.0], density=False)[0]
     avgQ = [np.asarray(a, dtype=np.float64) for a in avgQ]
     varQ = [np.asarray(v, dtype=np.float64) for v in varQ]
 
@@ -156,69 +154,84 @@ def _mean_ci(series, rng):
     return [mean, ci]
 
 
+def _shell_chunks(obj, subInds, nPops, chunk_bytes):
+    """(t0, waters[k, n or n*lenWat, 3], boxes, len_wat, pop_pos, pop_off) per chunk of a trajectory, for the shell drivers"""
+    watInds, _, lenWat = obj.getWatInds()
+    watInds = np.asarray(watInds)
+    nW = len(watInds)
+    regular = nW > 0 and lenWat > 0 and np.array_equal(watInds, watInds[0] + lenWat * np.arange(nW))
+    span = slice(int(watInds[0]), int(watInds[0]) + lenWat * nW) if regular else None
+    select = None if nPops else (span if regular else watInds)
+    for t0, xyz, boxes in (_frame_chunks(obj.traj, select, chunk_bytes) if nW else ()):
+        if nPops:
+            waters = np.ascontiguousarray(xyz[:, span] if regular else xyz[:, watInds])
+            pop_pos, pop_off = engine.pack_populations(xyz, [subInds[t0 + k] for k in range(len(xyz))], nPops)
+        else:
+            waters, pop_pos, pop_off = xyz, None, None
+        yield t0, waters, boxes, (lenWat if regular else 1), pop_pos, pop_off
+
+
 def threeBodyCalc(topFile, trajFile=None, subInds=None, nPops=0, solResName='(!:WAT)', watResName='(:WAT)',
-                  nBins=500, stride=1, output2D=False, outPrefix='3bDistribution_', rng=None, write=True):
+                  nBins=500, stride=1, output2D=False, outPrefix='3bDistribution_', rng=None, write=True, chunk_bytes=None):
     """orderParam_lib.py:1269-1424: three-body angle distribution (wp.getCosAngs, 3.413 A shell) per
     frame and population, tetrahedralMetrics statistics with block-average CIs, and the pooled
     histogram written to 3bDistribution_<j>.txt.  Returns (pTet, avgCos, varCos, entropy, nWats), each
-    [mean, CI] over the populations.  The matplotlib (theta, Nc) plot of output2D=True is outside this
-    build's scope and is skipped."""
+    [mean, CI] over the populations.
+
+    The frame loop (opl:1312-1353) runs on the GPU: every chunk of the trajectory is one wol_cos_angs_traj call, which
+    reduces each frame's angles to what tetrahedralMetrics keeps of them (500-bin histogram, count, count and cosine sums
+    of the angles in [100, 120]); the angles themselves never leave the device.  The matplotlib (theta, Nc) plot of
+    output2D=True is outside this build's scope and is skipped."""
     obj = _as_traj_object(topFile, trajFile, stride, solResName, watResName)
-    xyz, boxes, watInds = _frames_of(obj)
-    nT = len(xyz)
-    stats = {k: [np.zeros(nT) for _ in range(nPops + 1)] for k in ("nWats", "pTet", "avgCos", "varCos", "entropy")}
-    angles = [[] for _ in range(nPops + 1)]
-    for t in range(nT):
-        watPos = np.ascontiguousarray(xyz[t][watInds])
-        for j in range(nPops + 1):
-            sub = watPos if j == 0 else xyz[t][subInds[t][j - 1]]
-            jAngles, _ = wp.getCosAngs(sub, watPos, boxes[t])
-            angles[j].append(jAngles)
-            stats["nWats"][j][t] = len(watInds) if j == 0 else len(subInds[t][j - 1])
-            if len(jAngles):
-                _, _, a, b, c_, d = wp.tetrahedralMetrics(jAngles, nBins=nBins)
-                stats["pTet"][j][t] = a; stats["avgCos"][j][t] = b
-                stats["varCos"][j][t] = c_; stats["entropy"][j][t] = d
+    watInds = np.asarray(obj.getWatInds()[0])
+    stats = {k: [[] for _ in range(nPops + 1)] for k in ("nWats", "pTet", "avgCos", "varCos", "entropy")}
+    pooled = [np.zeros(nBins, dtype=np.int64) for _ in range(nPops + 1)]
+    for t0, waters, boxes, len_wat, pop_pos, pop_off in _shell_chunks(obj, subInds, nPops, chunk_bytes):
+        res = engine.cos_angs_traj(waters, boxes, len_wat=len_wat, pop_pos=pop_pos, pop_off=pop_off, npops=nPops, nbins=nBins)
+        for k in range(len(waters)):
+            for j in range(nPops + 1):
+                _, a, b, c_, d = res.metrics(k, j)
+                stats["nWats"][j].append(len(watInds) if j == 0 else len(subInds[t0 + k][j - 1]))
+                stats["pTet"][j].append(a); stats["avgCos"][j].append(b)
+                stats["varCos"][j].append(c_); stats["entropy"][j].append(d)
+                pooled[j] += res.hist[k, j]
+    stats = {k: [np.asarray(x, dtype=np.float64) for x in v] for k, v in stats.items()}
     out = {k: _mean_ci(v, rng) for k, v in stats.items()}
-    pooled = []
+    bins = np.linspace(0.0, 180.0, nBins + 1)
     for j in range(nPops + 1):
-        allj = np.concatenate(angles[j]) if angles[j] else np.array([])
-        pooled.append(allj)
-        if write and len(allj):
-            angDist, bins, *_ = wp.tetrahedralMetrics(allj, nBins=nBins)
-            np.savetxt(outPrefix + str(j) + '.txt', np.stack([0.5 * (bins[:-1] + bins[1:]), angDist], axis=1),
+        if write and pooled[j].sum():
+            np.savetxt(outPrefix + str(j) + '.txt', np.stack([0.5 * (bins[:-1] + bins[1:]), pooled[j]], axis=1),
                        header='3-body angle (deg)    frequency', fmt="%.3e")
-    threeBodyCalc.last_angles = pooled
+    threeBodyCalc.last_hist = pooled
+    threeBodyCalc.last_series = stats
     return out["pTet"], out["avgCos"], out["varCos"], out["entropy"], out["nWats"]
 
 
 def lsiCalc(topFile, trajFile=None, subInds=None, nPops=0, solResName='(!:WAT)', watResName='(:WAT)', stride=1,
-            outPrefix='lsiDistribution_', rng=None, write=True):
+            outPrefix='lsiDistribution_', rng=None, write=True, chunk_bytes=None):
     """orderParam_lib.py:1586-1663: local structure index (wp.getLSI) per frame and population, mean and
     variance with block-average CIs, pooled 500-bin histogram on [0, 0.3] A^2 written to
-    lsiDistribution_<j>.txt.  Returns (avgLSI, varLSI), each [mean, CI]."""
+    lsiDistribution_<j>.txt.  Returns (avgLSI, varLSI), each [mean, CI].
+
+    The frame loop (opl:1618-1640) runs on the GPU, one wol_lsi_traj call per chunk of the trajectory."""
     obj = _as_traj_object(topFile, trajFile, stride, solResName, watResName)
-    xyz, boxes, watInds = _frames_of(obj)
-    nT = len(xyz)
-    avgLSI = [np.zeros(nT) for _ in range(nPops + 1)]
-    varLSI = [np.zeros(nT) for _ in range(nPops + 1)]
-    vals = [[] for _ in range(nPops + 1)]
-    for t in range(nT):
-        watPos = np.ascontiguousarray(xyz[t][watInds])
+    avgLSI = [[] for _ in range(nPops + 1)]
+    varLSI = [[] for _ in range(nPops + 1)]
+    pooled = np.zeros((nPops + 1, 500), dtype=np.int64)
+    for t0, waters, boxes, len_wat, pop_pos, pop_off in _shell_chunks(obj, subInds, nPops, chunk_bytes):
+        res = engine.lsi_traj(waters, boxes, lowCut=0.0, highCut=3.7, len_wat=len_wat, pop_pos=pop_pos, pop_off=pop_off, npops=nPops)
+        pooled += res.hist
         for j in range(nPops + 1):
-            sub = watPos if j == 0 else xyz[t][subInds[t][j - 1]]
-            jLSI, _ = wp.getLSI(sub, watPos, boxes[t], lowCut=0.0, highCut=3.7)
-            vals[j].append(jLSI)
-            avgLSI[j][t] = np.mean(jLSI); varLSI[j][t] = np.var(jLSI)
-    pooled = []
+            avgLSI[j].extend(res.mean[:, j]); varLSI[j].extend(res.var[:, j])
+    avgLSI = [np.asarray(a, dtype=np.float64) for a in avgLSI]
+    varLSI = [np.asarray(v, dtype=np.float64) for v in varLSI]
+    bins = np.linspace(0.0, 0.3, 501)
     for j in range(nPops + 1):
-        allj = np.concatenate(vals[j]) if vals[j] else np.array([])
-        pooled.append(allj)
         if write:
-            lsiDist, bins = np.histogram(allj, bins=500, range=[0.0, 0.3], density=False)
-            np.savetxt(outPrefix + str(j) + '.txt', np.stack([0.5 * (bins[:-1] + bins[1:]), lsiDist], axis=1),
+            np.savetxt(outPrefix + str(j) + '.txt', np.stack([0.5 * (bins[:-1] + bins[1:]), pooled[j]], axis=1),
                        header='lsiVal [A^2]    frequency', fmt="%.3e")
-    lsiCalc.last_values = pooled
+    lsiCalc.last_hist = pooled
+    lsiCalc.last_series = (avgLSI, varLSI)
     return _mean_ci(avgLSI, rng), _mean_ci(varLSI, rng)
 
 

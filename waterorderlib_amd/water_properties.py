@@ -73,9 +73,11 @@ def getCosAngs(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.413, ctx=None):
     return ang, num
 
 
-def getLSI(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7, ctx=None):
+def getLSI(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7, ctx=None, full=False):
     """Local structure index of Shiratani & Sasai per water (water_properties.py:252-311).
-    Returns (lsiVals, numLSI); waters the reference skips are absent from lsiVals."""
+    Returns (lsiVals, numLSI); waters the reference skips are absent from lsiVals.  full=True (an extension): the LSI of
+    EVERY water of subPos, NaN where the reference skips it, instead of the compacted list."""
+    full_out = full
     Pos = _pos(Pos, "Pos")
     subPos = Pos if subPos is Pos else _pos(subPos, "subPos")
     box = _lib.box3(BoxDims)
@@ -83,13 +85,15 @@ def getLSI(subPos, Pos, BoxDims, lowCut=0.0, highCut=3.7, ctx=None):
     ns = len(subPos)
     num = np.zeros(ns, dtype=np.float64)
     if ns == 0 or len(Pos) == 0:
-        return np.array([]), num
+        return (np.full(ns, np.nan) if full_out else np.array([])), num
     sub = None if _same(subPos, Pos) else subPos
     full = np.empty(ns, dtype=np.float64)
     nvalid = C.c_int64(0)
     _lib.check(_lib.load().wol_lsi_frame(ctx.handle, _lib.ptr(Pos), len(Pos), _lib.ptr(sub), ns, _lib.ptr(box),
                                          float(lowCut), float(highCut), _lib.ptr(full), _lib.ptr(num),
                                          C.byref(nvalid)))
+    if full_out:
+        return full, num
     return full[~np.isnan(full)], num
 
 
