@@ -1109,13 +1109,24 @@ struct FrameFeeder {
         c = ctx; frames = fr; atom_stride = as; frame_stride = fs; T_frames = Tn; n = nw; host = is_host;
         pack = host && c->host_pack >= 1 && (atom_stride > 3 || (c->host_pack >= 2 && std::is_same<T, double>::value));
         narrow = pack && c->host_pack >= 2 && std::is_same<T, double>::value;
+        if (narrow) {
+            // a look at the first waters of the first frame decides whether narrowing is worth trying at all (every batch is
+            // still checked in full while it is packed)
+            const int probe = std::min(n, 4096);
+            for (int w = 0; w < probe && narrow; ++w) {
+                const T* r = frames + (int64_t)w * atom_stride;
+                narrow = ((T)(float)r[0] == r[0]) && ((T)(float)r[1] == r[1]) && ((T)(float)r[2] == r[2]);
+            }
+            if (!narrow && atom_stride == 3) pack = false;    // O-only frames that are not single precision: copied as they lie
+        }
         Fb = c->frames_per_batch;
         if (Fb <= 0) {
             if (host) {
                 // host frames: batches of ~256 MB of link traffic (at least 64 frames: the streaming sort wants that many), so
                 // the first copy -- the only one no kernel runs under -- stays a small part of the job
+                // (packed frames: shorter batches, ~64 MB -- the first batch's packing and copy run under nothing)
                 const double frame_bytes = pack ? 3.0 * n * sizeof(T) : (double)frame_stride * sizeof(T);
-                Fb = (int)std::fmin(4096.0, std::fmax(64.0, 256.0e6 / frame_bytes));
+                Fb = pack ? (int)std::fmin(4096.0, std::fmax(32.0, 64.0e6 / frame_bytes)) : (int)std::fmin(4096.0, std::fmax(64.0, 256.0e6 / frame_bytes));
                 const double per_frame = (double)n * bytes_per_water + 2.0 * frame_bytes;
                 Fb = (int)std::fmin((double)Fb, std::fmax(1.0, 6.0e9 / per_frame));
             } else {
