@@ -125,6 +125,7 @@ struct wol_ctx {
                              // more (smaller frames sort faster through row buckets: their second read comes out of L2), 2 = whenever it applies, 0 = never
     int stages = 2;          // pipe depth of the trajectory path: 2 = sort | proposal + certification, 3 = sort | proposal | certification
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
+    bool pair_tiled = true;         // RadialDistSame through the LDS-tiled pair kernel (option "pair_tiled"; 0 = the lane-per-water walk)
     bool check_props = false;       // diagnostic: poison the proposal arrays, count what the proposal kernel writes (k_check_props)
     DevBuf prop_counters;           // {keys written, proposals naming a slot outside the frame} since the option was switched on
     int64_t prop_expected = 0;      // waters the row kernel was given since then
@@ -1788,6 +1789,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->search_margin = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0.0;
+    } else if (k == "pair_tiled") {
+        c->pair_tiled = value != 0.0;
     } else if (k == "host_pack") {
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail(WOL_ERR_INVALID, "host_pack must be 0, 1 or 2");
         c->host_pack = (int)value;
@@ -2273,12 +2276,41 @@ static int pair_counts_impl(wol_ctx* c, const double* pos1, int n1, const double
     HIP_TRY(hipMemsetAsync(c->hist_stage.p, 0, sizeof(unsigned long long) * (size_t)totbins, c->stream));
     const size_t lds = sizeof(int) * (size_t)totbins;
     int grid = 0;
-    WOL_TRY(resident_grid(c, k_pair_hist, WOL_BLOCK, lds, (nq + WOL_BLOCK - 1) / WOL_BLOCK, &grid));
     std::pair<hipEvent_t, hipEvent_t> ev;
-    if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
-    hipLaunchKernelGGL(k_pair_hist, dim3(grid), dim3(WOL_BLOCK), lds, c->stream, sa, pos1 ? 0 : 1, binwidth, totbins,
-                       c->hist_stage.as<unsigned long long>());
-    if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    const FrameGrid* gh = c->grids_host.as<FrameGrid>();
+    const double reach = binwidth * (double)totbins;
+    if (!pos1 && sa.use_cells && c->pair_tiled && lds <= 16 * 1024 && reach < 60.0) {
+        // one set, pairs once: the LDS-tiled kernel (runs of cells along x, about a hundred waters per 128-lane block)
+        PairTileArgs pa;
+        pa.grid = sa.grid; pa.sorted = sa.sorted; pa.cell_start = sa.cell_start; pa.n = n2;
+        const double wpc = std::fmax((double)n2 / (double)gh->ncell, 0.05);
+        int cxrun = (int)std::fmax(1.0, std::floor(58.0 / wpc));
+        cxrun = std::min(cxrun, gh->nc[0]);
+        pa.ntx = (gh->nc[0] + cxrun - 1) / cxrun;
+        pa.cxrun = (gh->nc[0] + pa.ntx - 1) / pa.ntx;      // equalised
+        // fp32 coordinates are taken relative to the run's centre (nearest image to the centre): that is every lane's
+        // nearest image when no axis is shorter than twice (the tile's half extent + the reach)
+        pa.need_minimg = 0;
+        const double ext[3] = {0.5 * pa.cxrun * gh->cw[0], 0.5 * gh->cw[1], 0.5 * gh->cw[2]};
+        for (int k = 0; k < 3; ++k)
+            if (gh->box.L[k] < 2.0 * (ext[k] + reach) + 1.0) pa.need_minimg = 1;
+        pa.binwidth = binwidth; pa.totbins = totbins;
+        pa.cut2f = (float)(reach * reach * (1.0 + 1e-5) + 1e-3);
+        pa.hist = c->hist_stage.as<unsigned long long>();
+        const int64_t units = (int64_t)gh->nc[1] * gh->nc[2] * pa.ntx * (gh->lo[1] + gh->hi[1] + 1) * (gh->lo[2] + gh->hi[2] + 1);
+        if (pa.need_minimg) WOL_TRY(resident_grid(c, k_pair_hist_tiled<true>, WOL_PT_BLOCK, lds, units, &grid));
+        else WOL_TRY(resident_grid(c, k_pair_hist_tiled<false>, WOL_PT_BLOCK, lds, units, &grid));
+        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+        if (pa.need_minimg) hipLaunchKernelGGL(k_pair_hist_tiled<true>, dim3(grid), dim3(WOL_PT_BLOCK), lds, c->stream, pa);
+        else hipLaunchKernelGGL(k_pair_hist_tiled<false>, dim3(grid), dim3(WOL_PT_BLOCK), lds, c->stream, pa);
+        if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    } else {
+        WOL_TRY(resident_grid(c, k_pair_hist, WOL_BLOCK, lds, (nq + WOL_BLOCK - 1) / WOL_BLOCK, &grid));
+        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+        hipLaunchKernelGGL(k_pair_hist, dim3(grid), dim3(WOL_BLOCK), lds, c->stream, sa, pos1 ? 0 : 1, binwidth, totbins,
+                           c->hist_stage.as<unsigned long long>());
+        if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+    }
     HIP_TRY(hipMemcpyAsync(counts->data(), c->hist_stage.p, sizeof(long long) * (size_t)totbins, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());

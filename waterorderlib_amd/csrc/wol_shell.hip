@@ -318,6 +318,156 @@ k_willard(ShellArgs a, WillardArgs w) {
 // unordered pair is counted once (slot order instead of the reference's index order: the same pair set).
 // Zero distances are skipped (PairDistanceHistogram does; in the other two the reference writes counts(0)).
 // ---------------------------------------------------------------------------------------------
+// nbin = ceiling(sqrt(d2) / binwidth) (waterlib.f90:219-222) of an exact squared distance: guessed in fp32 and accepted
+// when d2 lies strictly inside the squared edges of that bin with a 1e-12 margin (which covers the roundings of the
+// reference's sqrt and division, so its ceiling is this bin); on or near an edge the reference's own expression decides
+__device__ __forceinline__ int wol_pair_bin_exact(double d2, double binwidth, float inv_wf) {
+    int k = (int)ceilf(__builtin_sqrtf((float)d2) * inv_wf);
+    const double lo = (double)(k - 1) * binwidth, hi = (double)k * binwidth;
+    if (!(d2 > lo * lo * (1.0 + 1e-12) && d2 < hi * hi * (1.0 - 1e-12))) k = (int)ceil(sqrt(d2) / binwidth);
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same counts for ONE set (RadialDistSame: pairs once), LDS-tiled.  A 128-thread block owns the waters of a run of
+// cells along x (one lane each) and sweeps the cell rows in reach, staged into LDS as float32 coordinates relative to the
+// run's centre (the image nearest the centre, taken in fp64; 16 bytes per candidate with its slot): every lane looks at
+// the same candidate in the same iteration -- a broadcast LDS read and uniform trip counts, where the lane-per-water
+// walk pays the longest cell of 64 different walks in every wave and a chain of dependent L2 round trips.
+// The fp32 squared distance only PROPOSES the bin: it is taken when it lies inside the bin's squared edges by more than a
+// bound on its own error (coordinates rounded at <= 64 A: 4e-6 A each; three products), else -- about one pair in a
+// thousand -- the exact minimum-image distance of the fp64 records decides, as in k_pair_hist.  So the integer counts are
+// those of the exact kernel.
+// ---------------------------------------------------------------------------------------------
+#define WOL_PT_BLOCK 64
+#define WOL_PT_CAP 512       // staged candidates per sweep (8 KiB): one row of the walk is ~150
+struct PairTileArgs {
+    const FrameGrid* grid;
+    const double4* sorted;
+    const int* cell_start;
+    int n;
+    int cxrun, ntx;          // cells per run along x, runs per cell row
+    int need_minimg;         // the box is too small for "nearest image to the run's centre" to be every lane's nearest image
+    double binwidth;
+    int totbins;
+    float cut2f;             // (totbins * binwidth)^2 + margin: beyond it a pair cannot fall into a bin
+    unsigned long long* hist;
+};
+
+template <bool MINIMG>
+__global__ void __launch_bounds__(WOL_PT_BLOCK)
+k_pair_hist_tiled(PairTileArgs a) {
+    extern __shared__ int lds_hist[];                 // [totbins]
+    __shared__ float4 cand[WOL_PT_CAP];               // (x, y, z relative to the centre, slot)
+    const FrameGrid& g = *a.grid;
+    const int tid = threadIdx.x;
+    const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
+    wol_hist_zero(lds_hist, a.totbins);
+    const double4* __restrict__ sp = a.sorted;
+    const int* __restrict__ cs = a.cell_start + g.cell_base;
+    const float inv_wf = (float)(1.0 / a.binwidth), wf = (float)a.binwidth;
+    const float Lf[3] = {(float)g.box.L[0], (float)g.box.L[1], (float)g.box.L[2]};
+    const float ibf[3] = {(float)g.box.ib[0], (float)g.box.ib[1], (float)g.box.ib[2]};
+    // work unit = (run of cells, one (dz, dy) row of the walk): units are dealt round-robin to a grid of resident blocks, so
+    // the launch ends evenly whatever the number of runs (whole tiles per block left the last round of blocks half empty)
+    const int wy = g.lo[1] + g.hi[1] + 1, wz = g.lo[2] + g.hi[2] + 1, nwalk = wy * wz;
+    const int64_t nunits = (int64_t)nz * ny * a.ntx * nwalk;
+    for (int64_t u = blockIdx.x; u < nunits; u += gridDim.x) {
+        const int tile = (int)(u / nwalk), wr = (int)(u - (int64_t)tile * nwalk);
+        const int row = tile / a.ntx, tx = tile - row * a.ntx;
+        const int cz = row / ny, cy = row - cz * ny;
+        const int cx0 = tx * a.cxrun, cxe = min(a.cxrun, nx - cx0);
+        if (cxe <= 0) continue;
+        const int dz = wr / wy - g.lo[2], dy = wr - (wr / wy) * wy - g.lo[1];
+        const int qb = cs[row * nx + cx0], qe = cs[row * nx + cx0 + cxe];
+        if (qe <= qb) continue;
+        const double ctr[3] = {((double)cx0 + 0.5 * (double)cxe) * g.cw[0], ((double)cy + 0.5) * g.cw[1], ((double)cz + 0.5) * g.cw[2]};
+        // candidate cells along x: the union of the lanes' walks, [cx0 - lo, cx0 + cxe - 1 + hi], or the whole row
+        const int xa = cx0 - g.lo[0], xb = cx0 + cxe - 1 + g.hi[0];
+        const bool whole = xb - xa + 1 >= nx;
+        // every unordered pair is counted once, from the water with the lower slot (slots run row by row): a candidate row
+        // below the lanes' own holds no partner that counts here -- half of the walk's rows are skipped whole
+        const int crow = wol_wrap_cell(cz + dz, nz) * ny + wol_wrap_cell(cy + dy, ny);
+        if (crow < row) continue;
+        const int* __restrict__ rw = cs + crow * nx;
+        int p0a, p0b, p1a = 0, p1b = 0;
+        if (whole) { p0a = 0; p0b = nx; }
+        else if (xa < 0) { p0a = xa + nx; p0b = nx; p1a = 0; p1b = xb + 1; }
+        else if (xb >= nx) { p0a = xa; p0b = nx; p1a = 0; p1b = xb - nx + 1; }
+        else { p0a = xa; p0b = xb + 1; }
+        for (int q0 = qb; q0 < qe; q0 += WOL_PT_BLOCK) {
+            const int qs = q0 + tid;
+            const bool live = qs < qe;
+            double c[3] = {0.0, 0.0, 0.0};
+            float qx = 0.f, qy = 0.f, qz = 0.f;
+            if (live) {
+                const double4 v = sp[qs];
+                c[0] = v.x; c[1] = v.y; c[2] = v.z;
+                qx = (float)wol_minimg1(v.x - ctr[0], g.box.L[0], g.box.ib[0]);
+                qy = (float)wol_minimg1(v.y - ctr[1], g.box.L[1], g.box.ib[1]);
+                qz = (float)wol_minimg1(v.z - ctr[2], g.box.L[2], g.box.ib[2]);
+            }
+            int fill = 0;                                       // candidates staged and not yet swept (block-uniform)
+            auto sweep = [&]() {
+                __syncthreads();
+                if (live) {
+                    for (int i = 0; i < fill; ++i) {
+                        const float4 p = cand[i];
+                        const int slot = __float_as_int(p.w);
+                        float dx = p.x - qx, dy_ = p.y - qy, dz_ = p.z - qz;
+                        if (MINIMG) {
+                            dx -= Lf[0] * rintf(dx * ibf[0]); dy_ -= Lf[1] * rintf(dy_ * ibf[1]); dz_ -= Lf[2] * rintf(dz_ * ibf[2]);
+                        }
+                        const float d2f = __builtin_fmaf(dz_, dz_, __builtin_fmaf(dy_, dy_, dx * dx));
+                        if (d2f >= a.cut2f || slot <= qs) continue;     // out of range, or the pair belongs to the other water
+                        const float kf = ceilf(__builtin_sqrtf(d2f) * inv_wf);
+                        const float lo = (kf - 1.0f) * wf, hi = kf * wf;
+                        const float m = 4.0e-4f + 2.0e-6f * d2f;        // bound on |d2f - d2| (+ the edges' own rounding)
+                        int k = (int)kf;
+                        if (!(d2f > __builtin_fmaf(lo, lo, m) && d2f < __builtin_fmaf(hi, hi, -m))) {
+                            const double4 w = sp[slot];
+                            const double ex = wol_minimg1(w.x - c[0], g.box.L[0], g.box.ib[0]);
+                            const double ey = wol_minimg1(w.y - c[1], g.box.L[1], g.box.ib[1]);
+                            const double ez = wol_minimg1(w.z - c[2], g.box.L[2], g.box.ib[2]);
+                            const double d2 = wol_sumsq(ex, ey, ez);
+                            if (!(d2 > 0.0)) continue;
+                            k = wol_pair_bin_exact(d2, a.binwidth, inv_wf);
+                        }
+                        if (k >= 1 && k <= a.totbins) atomicAdd(&lds_hist[k - 1], 1);
+                    }
+                }
+                __syncthreads();
+                fill = 0;
+            };
+#pragma unroll
+            for (int piece = 0; piece < 2; ++piece) {
+                const int ca = piece ? p1a : p0a, cb = piece ? p1b : p0b;
+                if (cb <= ca) continue;
+                int b = rw[ca];
+                const int e = rw[cb];
+                while (b < e) {
+                    const int take = min(e - b, WOL_PT_CAP - fill);
+                    for (int j = tid; j < take; j += WOL_PT_BLOCK) {
+                        const double4 v = sp[b + j];
+                        float4 r;
+                        r.x = (float)wol_minimg1(v.x - ctr[0], g.box.L[0], g.box.ib[0]);
+                        r.y = (float)wol_minimg1(v.y - ctr[1], g.box.L[1], g.box.ib[1]);
+                        r.z = (float)wol_minimg1(v.z - ctr[2], g.box.L[2], g.box.ib[2]);
+                        r.w = __int_as_float(b + j);
+                        cand[fill + j] = r;
+                    }
+                    fill += take;
+                    b += take;
+                    if (fill == WOL_PT_CAP) sweep();
+                }
+            }
+            if (fill > 0) sweep();
+        }
+    }
+    __syncthreads();
+    wol_hist_flush(lds_hist, a.totbins, a.hist);
+}
+
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long long* __restrict__ hist) {
     extern __shared__ int lds_hist[];
@@ -331,12 +481,7 @@ k_pair_hist(ShellArgs a, int same, double binwidth, int totbins, unsigned long l
         wol_for_each_candidate(a, c, [&](int slot, double d2, double, double, double) {
             if (same && slot <= q) return;
             if (!(d2 > 0.0)) return;
-            // nbin = ceiling(sqrt(d2) / binwidth): guessed in fp32 and accepted when d2 lies strictly inside the squared
-            // edges of that bin with a 1e-12 margin (which covers the roundings of the reference's sqrt and division, so
-            // its ceiling is this bin); on or near an edge the reference's own expression decides
-            int k = (int)ceilf(__builtin_sqrtf((float)d2) * inv_wf);
-            const double lo = (double)(k - 1) * binwidth, hi = (double)k * binwidth;
-            if (!(d2 > lo * lo * (1.0 + 1e-12) && d2 < hi * hi * (1.0 - 1e-12))) k = (int)ceil(sqrt(d2) / binwidth);
+            const int k = wol_pair_bin_exact(d2, binwidth, inv_wf);
             if (k >= 1 && k <= totbins) atomicAdd(&lds_hist[k - 1], 1);
         });
     }

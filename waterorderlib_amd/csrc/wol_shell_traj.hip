@@ -68,21 +68,41 @@ __device__ __forceinline__ void wol_traj_candidates(const FrameGrid& g, const do
     int cc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) cc[k] = wol_cell_coord(c[k], g.box.ib[k], g.nc[k], nullptr);
+    // the cells of one x run are contiguous in the sorted array: a (dz, dy) row of the walk is one span of records, or two
+    // where the run wraps around the box -- a fifth of the cell-table look-ups of a cell-by-cell walk, and loops long
+    // enough to keep four records in flight
+    const int nx = g.nc[0];
+    const int xa = cc[0] - g.lo[0], xb = cc[0] + g.hi[0];       // first and last cell of the run, before wrapping
+    const bool whole = g.lo[0] + g.hi[0] + 1 >= nx;
     for (int dz = -g.lo[2]; dz <= g.hi[2]; ++dz) {
         const int cz = wol_wrap_cell(cc[2] + dz, g.nc[2]);
         for (int dy = -g.lo[1]; dy <= g.hi[1]; ++dy) {
             const int cy = wol_wrap_cell(cc[1] + dy, g.nc[1]);
-            // the cells of one x run are contiguous in the sorted array unless the run wraps: walk it cell by cell
-            for (int dx = -g.lo[0]; dx <= g.hi[0]; ++dx) {
-                const int cx = wol_wrap_cell(cc[0] + dx, g.nc[0]);
-                const int cell = (cz * g.nc[1] + cy) * g.nc[0] + cx;
-                const int b = cs[cell], e = cs[cell + 1];
-                for (int j = b; j < e; ++j) {
-                    const double4 v = sp[j];
-                    const double ex = wol_minimg1(v.x - c[0], g.box.L[0], g.box.ib[0]);
-                    const double ey = wol_minimg1(v.y - c[1], g.box.L[1], g.box.ib[1]);
-                    const double ez = wol_minimg1(v.z - c[2], g.box.L[2], g.box.ib[2]);
-                    f(j, wol_sumsq(ex, ey, ez));
+            const int* __restrict__ row = cs + (cz * g.nc[1] + cy) * nx;
+            // piece 0: [p0a, p0b), piece 1: [p1a, p1b) (empty unless the run wraps)
+            int p0a, p0b, p1a = 0, p1b = 0;
+            if (whole) { p0a = 0; p0b = nx; }
+            else if (xa < 0) { p0a = xa + nx; p0b = nx; p1a = 0; p1b = xb + 1; }
+            else if (xb >= nx) { p0a = xa; p0b = nx; p1a = 0; p1b = xb - nx + 1; }
+            else { p0a = xa; p0b = xb + 1; }
+#pragma unroll
+            for (int piece = 0; piece < 2; ++piece) {
+                const int ca = piece ? p1a : p0a, cb = piece ? p1b : p0b;
+                if (cb <= ca) continue;
+                const int b = row[ca], e = row[cb];
+                for (int j = b; j < e; j += 4) {
+                    double4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = sp[min(j + u, e - 1)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (j + u < e) {
+                            const double ex = wol_minimg1(v[u].x - c[0], g.box.L[0], g.box.ib[0]);
+                            const double ey = wol_minimg1(v[u].y - c[1], g.box.L[1], g.box.ib[1]);
+                            const double ez = wol_minimg1(v[u].z - c[2], g.box.L[2], g.box.ib[2]);
+                            f(j + u, wol_sumsq(ex, ey, ez));
+                        }
+                    }
                 }
             }
         }
