@@ -210,32 +210,43 @@ def test_breathing_boxes_reuse_tile_tables(oracle):
 
 def test_host_pipeline_equals_device_resident_bit_for_bit():
     """wol_q_traj with host frames: double-buffered staging (several batches, the copy of one under the kernels of the
-    previous), TIP4P-interleaved frames read through the atom stride; float32 wire format; per-water q on and off"""
+    previous), TIP4P-interleaved frames; every wire format of option host_pack -- whole interleaved frames (0), O rows
+    packed by host threads (1), packed and narrowed to float32 when every coordinate is exactly one (2, the default) --
+    gives the device-resident results bit for bit; per-water q on and off; the link carries what the mode says"""
     import torch
     from waterorderlib_amd import _lib, engine, synth
     xyz, boxes = synth.water_frames(3000, 45, seed=88, len_wat=4)
-    dev = engine.tet_order_traj(torch.from_numpy(xyz).cuda(), boxes, len_wat=4, want_q=True)
-    torch.cuda.synchronize()
+    xyz_sp = xyz.astype(np.float32).astype(np.float64)          # a trajectory read from a single-precision file
     ctx = _lib.Context(0)
-    for fpb in (8, 16, 0):                       # 6 batches (last one ragged), 3 batches, automatic (one batch)
-        ctx.set_option("frames_per_batch", fpb)
-        for want_q in (True, False):
-            res = engine.tet_order_traj(xyz, boxes, len_wat=4, want_q=want_q, ctx=ctx)
-            assert np.array_equal(res.qhist, dev.qhist.cpu().numpy()) and np.array_equal(res.dhist, dev.dhist.cpu().numpy())
-            assert np.array_equal(res.mean, dev.mean.cpu().numpy()) and np.array_equal(res.var, dev.var.cpu().numpy())
-            if want_q:
-                assert np.array_equal(res.q, dev.q.cpu().numpy())
-        moved = ctx.counter("h2d_bytes")
-        assert 0.99 * xyz.nbytes <= moved <= xyz.nbytes       # whole interleaved frames cross the link, once
-    # back-to-back calls reuse the staging sets: the second must not overtake the first's kernels
-    a = engine.tet_order_traj(xyz[:20], boxes[:20], len_wat=4, want_q=True, ctx=ctx)
-    b = engine.tet_order_traj(xyz[20:], boxes[20:], len_wat=4, want_q=True, ctx=ctx)
-    assert np.array_equal(np.concatenate([a.q, b.q]), dev.q.cpu().numpy())
-    x32 = xyz.astype(np.float32)
-    ctx.set_option("frames_per_batch", 8)
-    r32 = engine.tet_order_traj(x32, boxes, len_wat=4, want_q=True, ctx=ctx)
-    d32 = engine.tet_order_traj(torch.from_numpy(x32).cuda(), boxes, len_wat=4, want_q=True)
-    assert np.array_equal(r32.q, d32.q.cpu().numpy()) and np.array_equal(r32.qhist, d32.qhist.cpu().numpy())
+    for frames, sp in ((xyz, False), (xyz_sp, True)):
+        dev = engine.tet_order_traj(torch.from_numpy(frames).cuda(), boxes, len_wat=4, want_q=True)
+        torch.cuda.synchronize()
+        for pack, threads in ((0, 0), (1, 3), (2, 0)):
+            ctx.set_option("host_pack", pack)
+            ctx.set_option("host_threads", threads)
+            for fpb in (8, 16, 0):                       # 6 batches (last one ragged), 3 batches, automatic
+                ctx.set_option("frames_per_batch", fpb)
+                for want_q in (True, False):
+                    res = engine.tet_order_traj(frames, boxes, len_wat=4, want_q=want_q, ctx=ctx)
+                    assert np.array_equal(res.qhist, dev.qhist.cpu().numpy()) and np.array_equal(res.dhist, dev.dhist.cpu().numpy())
+                    assert np.array_equal(res.mean, dev.mean.cpu().numpy()) and np.array_equal(res.var, dev.var.cpu().numpy())
+                    if want_q:
+                        assert np.array_equal(res.q, dev.q.cpu().numpy())
+                moved = ctx.counter("h2d_bytes")
+                o_rows = frames.nbytes // 4                  # the O rows of TIP4P frames
+                if pack == 0:
+                    assert 0.99 * frames.nbytes <= moved <= frames.nbytes       # whole interleaved frames cross the link, once
+                elif pack == 1 or not sp:
+                    assert moved == o_rows                                      # the 24-byte O rows only
+                else:
+                    assert moved == o_rows // 2                                 # ... as float32: exact for these frames
+        # float32 frames keep their storage type on the wire and in the results
+        f32 = frames.astype(np.float32)
+        ctx.set_option("host_pack", 2); ctx.set_option("frames_per_batch", 16)
+        r32 = engine.tet_order_traj(f32, boxes, len_wat=4, want_q=True, ctx=ctx)
+        d32 = engine.tet_order_traj(torch.from_numpy(f32).cuda(), boxes, len_wat=4, want_q=True)
+        assert np.array_equal(r32.qhist, d32.qhist.cpu().numpy()) and np.array_equal(r32.q, d32.q.cpu().numpy())
+        assert ctx.counter("h2d_bytes") == f32.nbytes // 4
     ctx.close()
 
 

@@ -100,7 +100,7 @@ struct wol_ctx {
     // (gathers + fp64) on `stream`, the stream the caller sees.  Each batch owns one set of intermediate arrays; events
     // hand the sets from stage to stage.
     struct SortSet {
-        DevBuf sorted, sorted32, cells, grids, level, cnt4, prop, prop_key, work;
+        DevBuf sorted, sorted32, cells, grids, level, cnt4, prop, prop_key, work, tile_any;
         hipEvent_t sorted_ev = nullptr;    // recorded on the sort stream when the set is filled
         hipEvent_t searched_ev = nullptr;  // recorded on the search stream when the proposals are written
         hipEvent_t rows_ev = nullptr, level_ev = nullptr;   // first sort level done / density level picked (beside the second level)
@@ -125,6 +125,7 @@ struct wol_ctx {
                              // more (smaller frames sort faster through row buckets: their second read comes out of L2), 2 = whenever it applies, 0 = never
     int stages = 2;          // pipe depth of the trajectory path: 2 = sort | proposal + certification, 3 = sort | proposal | certification
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
+    bool skip_empty = true;         // the proposal kernel skips tile rows without any water (option "skip_empty_tiles")
     bool pair_tiled = true;         // RadialDistSame through the LDS-tiled pair kernel (option "pair_tiled"; 0 = the lane-per-water walk)
     bool check_props = false;       // diagnostic: poison the proposal arrays, count what the proposal kernel writes (k_check_props)
     DevBuf prop_counters;           // {keys written, proposals naming a slot outside the frame} since the option was switched on
@@ -192,7 +193,10 @@ void build_tile_tables(const int nc[3], int n, int rows_block, TileTables* t) {
     // waters as fit one sweep of the block (one lane per water) while the halo'd tile ((sz+2) layers
     // of (ry+2) x (sx+2) cells, each padded to an even count, +15 %) fits the LDS pair buffer and the
     // row tables; among the fullest shapes the one with the smallest halo.
-    static const double lev_mult[WOL_NLEV] = {1.10, 1.35, 1.75, 2.4, 4.0, 8.0};  // densest tile-sized window / box average
+    // densest tile-sized window / box average.  (Twelve levels in steps of 19 % were tried in round 3: tiles sized closer to
+    // the local density, but the shapes the search then picks for slabs -- 5 x 27 cells instead of 8 x 18 -- have half
+    // again as many triples per tile: 1.57 against 1.25 ms on the config-5 slab.  The lane-fill score does not see that.)
+    static const double lev_mult[WOL_NLEV] = {1.10, 1.35, 1.75, 2.4, 4.0, 8.0};
     t->nlev = WOL_NLEV;
     t->ntiles = 0;
     t->max_sx = t->max_ry = t->max_sz = 1;
@@ -467,7 +471,7 @@ struct BatchPlan {
     int n_cell_frames = 0;
     std::vector<int> brute_frames;     // frames without a grid (non-periodic axis, tiny inputs, forced): all-pairs kernels
     bool use_fast = false, rows_kernel = false, level_early = false, pipe = false;
-    int rows_block = 0, tiles_max = 0;
+    int rows_block = 0, tiles_max = 0, tile_any_stride = 0;
     float4* s32 = nullptr;
     unsigned* cnt4 = nullptr;
     hipStream_t ss = nullptr, qs = nullptr;   // the streams of the sort and of the proposal kernel
@@ -737,8 +741,14 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
                 HIP_TRY(hipEventRecord(S.rows_ev, ss));
                 HIP_TRY(hipStreamWaitEvent(c->grid_stream, S.rows_ev, 0));
+                int* tile_any = nullptr;
+                if (rows_kernel) {   // which (layer, tile row) pairs hold any water: the proposal kernel skips the others
+                    WOL_TRY(S.tile_any.ensure(sizeof(int) * (size_t)F * (size_t)(nrow_max + 1)));
+                    tile_any = S.tile_any.as<int>();
+                    bp->tile_any_stride = nrow_max + 1;
+                }
                 hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->grid_stream, S.grids.as<FrameGrid>(), S.cells.as<int>(),
-                                   c->layer_off.as<int>(), ro_stride, S.level.as<int>());
+                                   c->layer_off.as<int>(), ro_stride, S.level.as<int>(), tile_any, nrow_max + 1);
                 HIP_TRY(hipEventRecord(S.level_ev, c->grid_stream));
                 level_early = true;
             }
@@ -836,10 +846,13 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             }
             if (!level_early) {
                 WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
-                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, (const int*)nullptr, 0, S.level.as<int>());
+                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, (const int*)nullptr, 0, S.level.as<int>(),
+                                   (int*)nullptr, 0);
             }
             FastArgs fa;
             fa.level = S.level.as<int>();
+            fa.tile_any = (level_early && rows_kernel && bp.tile_any_stride && c->skip_empty) ? S.tile_any.as<int>() : nullptr;
+            fa.tile_any_stride = bp.tile_any_stride;
             fa.grids = a.grids; fa.sorted = a.sorted; fa.sorted32 = s32; fa.cell_start = a.cell_start;
             fa.n = n; fa.F = F; fa.highsq = highsq; fa.high = high; fa.out = out;
             fa.tiles_per_frame = tiles_max;
@@ -1705,7 +1718,7 @@ int wol_ctx_destroy(wol_ctx* c) {
     DevBuf* bufs[] = {&c->cellid, &c->rank, &c->qbuf, &c->in_stage,
                       &c->out_stage, &c->hist_stage, &c->small, &c->stat, &c->layer_off, &c->sort_tmp, &c->slow_list, &c->slow_count, &c->stamps, &c->scan_tot, &c->seg_tab};
     for (auto& S : c->sets) {
-        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release(); S.prop.release(); S.prop_key.release(); S.work.release();
+        S.sorted.release(); S.sorted32.release(); S.cells.release(); S.grids.release(); S.level.release(); S.cnt4.release(); S.prop.release(); S.prop_key.release(); S.work.release(); S.tile_any.release();
         if (S.rows_ev) (void)hipEventDestroy(S.rows_ev);
         if (S.level_ev) (void)hipEventDestroy(S.level_ev);
         if (S.searched_ev) (void)hipEventDestroy(S.searched_ev);
@@ -1789,6 +1802,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->search_margin = (int)value;
     } else if (k == "overlap") {
         c->overlap = value != 0.0;
+    } else if (k == "skip_empty_tiles") {
+        c->skip_empty = value != 0.0;
     } else if (k == "pair_tiled") {
         c->pair_tiled = value != 0.0;
     } else if (k == "host_pack") {
@@ -1855,10 +1870,18 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
     }
     if (std::string(key) == "tile_sx" || std::string(key) == "tile_ry" || std::string(key) == "tiles_per_frame") {
         // geometry of the proposal kernel's tiles for frame 0 of the last batch at density level 0 (diagnostic)
+        // ... at the density level the device picked for it
         const FrameGrid* g = c->grids_host.as<FrameGrid>();
-        *value = !g ? 0 : key[5] == 's' && key[4] == '_' ? (c->search_rows ? g->row_sx[0] : g->lev_sx[0])
-                          : key[5] == 'r' ? (c->search_rows ? g->row_ry[0] : g->lev_ry[0])
-                          : (c->search_rows ? g->row_ntiles[0] : g->lev_ntiles[0]);
+        int lv = 0;
+        if (g && c->last_set && c->last_set->level.p) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(&lv, c->last_set->level.p, sizeof(int), hipMemcpyDeviceToHost));
+            lv &= 0xFF;
+            if (lv < 0 || lv >= WOL_NLEV) lv = 0;
+        }
+        *value = !g ? 0 : key[5] == 's' && key[4] == '_' ? (c->search_rows ? g->row_sx[lv] : g->lev_sx[lv])
+                          : key[5] == 'r' ? (c->search_rows ? g->row_ry[lv] : g->lev_ry[lv])
+                          : (c->search_rows ? g->row_ntiles[lv] : g->lev_ntiles[lv]);
         return WOL_OK;
     }
     if (std::string(key) == "rows_block") {  // k_search_rows instantiation of the last batch (threads per block)
@@ -1871,7 +1894,7 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
             int v = 0;
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(&v, c->last_set->level.p, sizeof(int), hipMemcpyDeviceToHost));
-            *value = v;
+            *value = v & 0xFF;    // (bit 8: the frame has tile rows without any water)
         }
         return WOL_OK;
     }

@@ -75,7 +75,10 @@ struct FastArgs {
     unsigned long long* slow_list;  // (frame << 32 | sorted slot) of waters left to the exact kernel
     int* slow_count;
     int fast_q;             // 1: q straight from the cosines (no acos/deg/cos round trip); needs out.ang == null
-    const int* level;       // [F] density level picked by k_pick_level (index into FrameGrid::lev_*)
+    const int* level;       // [F] density level picked by k_pick_level (index into FrameGrid::lev_*) in the low byte; bit 8: the
+                            // frame has (layer, tile row) pairs without any water (tile_any says which)
+    const int* tile_any;    // [F][tile_any_stride] k_search_rows: 1 where tile row ty of layer cz (index cz * nty + ty) holds water, or null
+    int tile_any_stride;
     int4* prop;             // [F][n] by sorted slot: sorted slots of the four proposed neighbours
     int* prop_key;          // [F][n]: 4th key (d2 in key units) or -1 = not certifiable by keys
     int* work;              // k_search_rows: eight tile counters (one per XCD, 64 B apart; zeroed by the host) or null = static tile order
@@ -210,7 +213,7 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start, const int* __restrict__ row_off,
-             int ro_stride, int* __restrict__ level) {
+             int ro_stride, int* __restrict__ level, int* __restrict__ tile_any, int tile_any_stride) {
     __shared__ int rows[12288];
     __shared__ int smax[WOL_BLOCK];
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -244,6 +247,7 @@ k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_s
         if (tid < off) smax[tid] = max(smax[tid], smax[tid + off]);
         __syncthreads();
     }
+    __shared__ int s_lev, s_empty;
     if (tid == 0) {
         int lev = g.nlev - 1;
         if (ok) {
@@ -251,8 +255,27 @@ k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_s
             for (int l = g.nlev - 1; l >= 0; --l)
                 if (wpc <= g.lev_wpc[l]) lev = l;
         }
-        level[f] = lev;
+        s_lev = lev;
+        s_empty = 0;
     }
+    __syncthreads();
+    const int lev = s_lev;
+    // tile rows of the row-merged proposal kernel (ry cell rows of one layer) without any water -- the vacuum of a slab, the
+    // space around a droplet: flagged here, skipped there before a single table is built
+    if (tile_any && ok && nz * (int)g.row_nty[lev] <= tile_any_stride) {
+        const int ry = g.row_ry[lev], nty = g.row_nty[lev];
+        int* __restrict__ ta = tile_any + (int64_t)f * tile_any_stride;
+        for (int idx = tid; idx < nz * nty; idx += WOL_BLOCK) {
+            const int cz = idx / nty, ty = idx - cz * nty;
+            const int y0 = ty * ry, re = min(ry, ny - y0);
+            int sum = 0;
+            for (int y = 0; y < re; ++y) sum += rows[cz * ny + y0 + y];
+            ta[idx] = sum > 0 ? 1 : 0;
+            if (sum == 0) s_empty = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) level[f] = lev | ((tile_any && ok && s_empty) ? 0x100 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -290,14 +313,14 @@ k_search_fast(FastArgs a) {
     auto tiles_of = [&](int ff) -> int {
         if (ff >= a.F) return 0;
         const FrameGrid& gg = a.grids[ff];
-        return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.lev_ntiles[a.level[ff]];
+        return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.lev_ntiles[a.level[ff] & 0xFF];
     };
     int nt_f = tiles_of(f);
     for (;; tile += tstep) {
         while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
         if (f >= a.F) break;
         const FrameGrid& g = a.grids[f];
-        const int lev = a.level[f];
+        const int lev = a.level[f] & 0xFF;
         const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2];
         const int gsx = g.lev_sx[lev], gry = g.lev_ry[lev], gsz = g.lev_sz[lev];
         const int gntx = g.lev_ntx[lev], gnty = g.lev_nty[lev];

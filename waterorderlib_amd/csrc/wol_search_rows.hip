@@ -150,7 +150,7 @@ k_search_rows(FastArgs a) {
     auto tiles_of = [&](int ff) -> int {
         if (ff >= a.F) return 0;
         const FrameGrid& gg = a.grids[ff];
-        return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.row_ntiles[a.level[ff]];
+        return (gg.maxshell < 0 || !gg.fast_ok) ? 0 : gg.row_ntiles[a.level[ff] & 0xFF];
     };
     // Per-frame constants stay in scalar registers from tile to tile (a block walks ~20 tiles of a frame before it
     // moves on): re-reading the frame's grid and re-deriving them per tile, on the vector unit of every wave, was a
@@ -158,7 +158,7 @@ k_search_rows(FastArgs a) {
 #define WOL_SGPR_I(x) __builtin_amdgcn_readfirstlane((int)(x))
 #define WOL_SGPR_F(x) __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)(x))))
     int f_cur = -1;
-    int nx = 1, ny = 1, nz = 1, gsx = 1, gry = 1, gntx = 1, ntxy = 1, cell_base = 0, eps_units = 0;
+    int nx = 1, ny = 1, nz = 1, gsx = 1, gry = 1, gntx = 1, ntxy = 1, cell_base = 0, eps_units = 0, has_empty = 0;
     float inv_ntxy = 1.f, inv_gntx = 1.f, fxs = 0.f, fys = 0.f, fzs = 0.f, eps_a = 0.f, eps_b = 0.f;
     int nt_f = tiles_of(f);
     // Tile order.  Static (a.work == null): block b walks tiles b, b + grid, ... of its XCD's frames.  Dynamic: the blocks
@@ -184,14 +184,15 @@ k_search_rows(FastArgs a) {
             while (f < a.F && w >= w_base + nt_f) { w_base += nt_f; f += fstep; nt_f = tiles_of(f); }
             if (f >= a.F) break;
             tile = w - w_base;
-            if (tid == 0) w_next = atomicAdd(ctr, 1);   // (in flight until the end of this tile)
         } else {
             while (f < a.F && tile >= nt_f) { tile -= nt_f; f += fstep; nt_f = tiles_of(f); }
             if (f >= a.F) break;
         }
         if (f != f_cur) {
             const FrameGrid& g = a.grids[f];
-            const int lev = a.level[f];
+            const int levw = a.level[f];
+            const int lev = levw & 0xFF;
+            has_empty = WOL_SGPR_I(a.tile_any ? (levw >> 8) & 1 : 0);
             nx = WOL_SGPR_I(g.nc[0]); ny = WOL_SGPR_I(g.nc[1]); nz = WOL_SGPR_I(g.nc[2]);
             gsx = WOL_SGPR_I(g.row_sx[lev]); gry = WOL_SGPR_I(g.row_ry[lev]);
             gntx = WOL_SGPR_I(g.row_ntx[lev]);
@@ -211,6 +212,21 @@ k_search_rows(FastArgs a) {
         const int trem = tile - cz * ntxy;
         const int ty = (int)(((float)trem + 0.5f) * inv_gntx);
         const int tx = trem - ty * gntx;
+        // a tile row without any water (k_pick_level's flags; frames that have such rows say so in their level word, so
+        // a full box pays nothing here): nothing to propose, nothing to write
+        // (tile = (cz * nty + ty) * ntx + tx: the flag's index is the tile number without its tx.  The flag is fetched before
+        // the next tile number is drawn: a wait for it must not have to wait for that atomic's round trip as well)
+        int tile_flag = 1;
+        if (has_empty) tile_flag = a.tile_any[(int64_t)f * a.tile_any_stride + (int)(((float)(tile - tx) + 0.5f) * inv_gntx)];
+        if (dyn && tid == 0) w_next = atomicAdd(ctr, 1);   // (in flight until the end of this tile)
+        if (__builtin_amdgcn_readfirstlane(tile_flag) == 0) {   // nothing in this tile row: on to the next number
+            if (dyn) {
+                if (tid == 0) s_next = w_next;
+                __syncthreads();
+                w_next = s_next;
+            }
+            continue;
+        }
         const int x0 = tx * gsx, sxe = min(gsx, nx - x0);
         const int y0 = ty * gry, re = min(gry, ny - y0);
         const int ntrip = re + 2, nrows = 3 * ntrip;
