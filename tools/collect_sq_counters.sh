@@ -27,7 +27,7 @@ echo "pmc memory done"
 WAT=100000; FPS=256; DT=f64
 case "$FLAGS" in *"--config 5"*) WAT=500100; FPS=32; DT=f32;; esac
 # keep only what the summary needs (kernel names of torch's own kernels make the raw files large)
-python3 $R/tools/summarize_pmc.py $O $O/summary.json "{\"waters\": $WAT, \"frames_per_step\": $FPS, \"dtype\": \"$DT\", \"command\": \"bench.py --no-cpu-baseline --no-end-to-end --steps 4 --warmup 1 $FLAGS (stats pass: --steps 10 --warmup 2)\", \"units\": \"FETCH_SIZE / WRITE_SIZE in KiB per dispatch; SQ_* as rocprofv3 reports them (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles summed over waves / SIMDs; SQ_BUSY_CYCLES in cycles summed over the 32 shader engines; GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs); vgpr = VGPR_Count of the kernel-trace record (architected VGPRs allocated per lane, granule 8; AGPRs not included)\"}" > $O/summary.txt
+python3 $R/tools/summarize_pmc.py $O $O/summary.json "{\"waters\": $WAT, \"frames_per_step\": $FPS, \"dtype\": \"$DT\", \"command\": \"bench.py --no-cpu-baseline --no-end-to-end --steps 4 --warmup 1 $FLAGS (stats pass: --steps 10 --warmup 2)\", \"units\": \"FETCH_SIZE / WRITE_SIZE in KiB per dispatch; SQ_* as rocprofv3 reports them (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* in quad-cycles summed over waves / SIMDs; SQ_BUSY_CYCLES in cycles summed over the 32 shader engines; GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs); vgpr = VGPR_Count of rocprofv3's kernel-trace record, which on gfx950 reads HALF the registers allocated per lane (k_search_rows: 40 for the compiler's 80; k_finish_fast: 64 for 122 used / 128 allocated; k_sort_in_row: 52 for 102 / 104): compare DESIGN's figures, which are the compiler's (.vgpr_count, -Rpass-analysis=kernel-resource-usage)\"}" > $O/summary.txt
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
 find $O -name "*counter_collection.csv" -delete
 find $O -name "*kernel_trace.csv" -delete

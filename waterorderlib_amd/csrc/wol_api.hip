@@ -1569,7 +1569,7 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
     if (o.kind == 1 && boxes[0] > 0.0 && boxes[1] > 0.0 && boxes[2] > 0.0) {
         const double rho = (double)n / (boxes[0] * boxes[1] * boxes[2]);
         const double kexp = rho * (4.0 / 3.0) * WOL_PI * (high * high * high - low * low * low);
-        lsi_row = (int)std::fmin((double)WOL_TRAJ_LSI_ROWMAX, std::fmax((double)WOL_TRAJ_LSI_ROW, 2.0 * kexp + 8.0));
+        lsi_row = (int)std::fmin((double)WOL_TRAJ_LSI_ROWMAX, std::fmax((double)WOL_TRAJ_LSI_ROW, 1.6 * kexp + 5.0));
     }
     bool lsi_lds_set = false;
     WOL_TRY(feed.start());
@@ -1586,6 +1586,7 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
         ta.grids = S.grids.as<FrameGrid>(); ta.sorted = S.sorted.as<double4>(); ta.cell_start = S.cells.as<int>();
         ta.n = n; ta.F = F; ta.f0 = f0; ta.npops = npops;
         ta.lowsq = low * low; ta.highsq = high * high;
+        ta.reach = reach;
         ta.pts = d_pts; ta.pt_off = d_poff;
         ta.nbins = o.nbins; ta.hist_max = o.hist_max;
         ta.hist = c->pop_hist.as<unsigned long long>(); ta.stat = c->pop_stat.as<unsigned long long>();

@@ -21,6 +21,7 @@ struct TrajShellArgs {
     int f0;                      // first frame of the batch in the call (segments are numbered over the call)
     int npops;
     double lowsq, highsq;
+    double reach;                // largest distance that matters to the kernel (cut-off; LSI: + 3.7 A): decides rint vs anint
     // population queries: points [pt_off[t * npops + j], pt_off[t * npops + j + 1]) belong to (frame t, population j + 1)
     const double* pts;           // [total][3]
     const long long* pt_off;     // [T * npops + 1]
@@ -51,17 +52,33 @@ __device__ __forceinline__ TrajBlockMap wol_traj_block_map(int n, int F) {
     return m;
 }
 
-// candidates of a query point c in frame grid g: f(slot, d2) for every water whose exact minimum-image d2 can matter
-template <typename Fn>
-__device__ __forceinline__ void wol_traj_candidates(const FrameGrid& g, const double4* __restrict__ sp, const int* __restrict__ cs,
-                                                    int n, const double c[3], Fn f) {
+// minimum image with anint as the reference (round half away) or, where the caller has checked that no candidate in reach
+// can sit at exactly half a box length (every periodic edge longer than twice the reach), with rint: one instruction
+// instead of six, the same value for every candidate that can pass the caller's cut
+template <bool RINT>
+__device__ __forceinline__ double wol_traj_minimg(double d, double L, double ib) {
+    return RINT ? d - L * rint(d * ib) : wol_minimg1(d, L, ib);
+}
+
+__device__ __forceinline__ bool wol_traj_rint_ok(const FrameGrid& g, double reach) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (g.box.ib[k] != 0.0 && !(0.5 * g.box.L[k] > reach * 1.000001 + 1e-6)) ok = false;
+    return ok;
+}
+
+// candidates of a query point c in frame grid g: f(slot, d2, record) for every water whose exact minimum-image d2 can matter
+template <bool RINT, typename Fn>
+__device__ __forceinline__ void wol_traj_candidates_t(const FrameGrid& g, const double4* __restrict__ sp, const int* __restrict__ cs,
+                                                      int n, const double c[3], Fn f) {
     if (g.maxshell < 0) {
         for (int j = 0; j < n; ++j) {
             const double4 v = sp[j];
             const double dx = wol_minimg1(v.x - c[0], g.box.L[0], g.box.ib[0]);
             const double dy = wol_minimg1(v.y - c[1], g.box.L[1], g.box.ib[1]);
             const double dz = wol_minimg1(v.z - c[2], g.box.L[2], g.box.ib[2]);
-            f(j, wol_sumsq(dx, dy, dz));
+            f(j, wol_sumsq(dx, dy, dz), v);
         }
         return;
     }
@@ -69,8 +86,8 @@ __device__ __forceinline__ void wol_traj_candidates(const FrameGrid& g, const do
 #pragma unroll
     for (int k = 0; k < 3; ++k) cc[k] = wol_cell_coord(c[k], g.box.ib[k], g.nc[k], nullptr);
     // the cells of one x run are contiguous in the sorted array: a (dz, dy) row of the walk is one span of records, or two
-    // where the run wraps around the box -- a fifth of the cell-table look-ups of a cell-by-cell walk, and loops long
-    // enough to keep four records in flight
+    // where the run wraps around the box -- a fifth of the cell-table look-ups of a cell-by-cell walk; two records in
+    // flight (four cost a wave per SIMD in registers and gained nothing)
     const int nx = g.nc[0];
     const int xa = cc[0] - g.lo[0], xb = cc[0] + g.hi[0];       // first and last cell of the run, before wrapping
     const bool whole = g.lo[0] + g.hi[0] + 1 >= nx;
@@ -90,23 +107,30 @@ __device__ __forceinline__ void wol_traj_candidates(const FrameGrid& g, const do
                 const int ca = piece ? p1a : p0a, cb = piece ? p1b : p0b;
                 if (cb <= ca) continue;
                 const int b = row[ca], e = row[cb];
-                for (int j = b; j < e; j += 4) {
-                    double4 v[4];
+                for (int j = b; j < e; j += 2) {
+                    double4 v[2];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v[u] = sp[min(j + u, e - 1)];
+                    for (int u = 0; u < 2; ++u) v[u] = sp[min(j + u, e - 1)];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int u = 0; u < 2; ++u) {
                         if (j + u < e) {
-                            const double ex = wol_minimg1(v[u].x - c[0], g.box.L[0], g.box.ib[0]);
-                            const double ey = wol_minimg1(v[u].y - c[1], g.box.L[1], g.box.ib[1]);
-                            const double ez = wol_minimg1(v[u].z - c[2], g.box.L[2], g.box.ib[2]);
-                            f(j + u, wol_sumsq(ex, ey, ez));
+                            const double ex = wol_traj_minimg<RINT>(v[u].x - c[0], g.box.L[0], g.box.ib[0]);
+                            const double ey = wol_traj_minimg<RINT>(v[u].y - c[1], g.box.L[1], g.box.ib[1]);
+                            const double ez = wol_traj_minimg<RINT>(v[u].z - c[2], g.box.L[2], g.box.ib[2]);
+                            f(j + u, wol_sumsq(ex, ey, ez), v[u]);
                         }
                     }
                 }
             }
         }
     }
+}
+
+template <typename Fn>
+__device__ __forceinline__ void wol_traj_candidates(const FrameGrid& g, const double4* __restrict__ sp, const int* __restrict__ cs,
+                                                    int n, const double c[3], bool use_rint, Fn f) {
+    if (use_rint) wol_traj_candidates_t<true>(g, sp, cs, n, c, f);
+    else wol_traj_candidates_t<false>(g, sp, cs, n, c, f);
 }
 
 // neighbour as tetraCosAng sees it (waterlib.f90:881-883): centre + minimum-image vector
@@ -146,7 +170,7 @@ __device__ __forceinline__ void wol_traj_angle(double ang, int nbins, int* lds_h
 // results are those of np.histogram over wol_cos_angs's angles).
 // stat[seg] = {angles, angles in [100, 120], sum cos (hi, lo), sum cos^2 (hi, lo), -, -}
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WOL_TRAJ_BLOCK)
+__global__ void __launch_bounds__(WOL_TRAJ_BLOCK, 4)   // 4 blocks (16 waves) per CU: 128 VGPRs, 40 KB of LDS each
 k_cos_angs_traj(TrajShellArgs a) {
     extern __shared__ int lds_dyn[];                         // [nbins] histogram of the frame in flight
     __shared__ int nb_slot[WOL_TRAJ_BLOCK * WOL_TRAJ_KMAX];  // [wave][k][lane]: slot of neighbour k of the lane's water
@@ -164,6 +188,7 @@ k_cos_angs_traj(TrajShellArgs a) {
         const FrameGrid& g = a.grids[f];
         const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
         const int* __restrict__ cs = a.cell_start + g.cell_base;
+        const bool rint_ok = wol_traj_rint_ok(g, a.reach);
         AngAcc acc = {0ull, 0ull, 0ll, 0ll, 0ll, 0ll};
         for (int s0 = ((int)blockIdx.x % bm.G) * WOL_TRAJ_BLOCK; s0 < a.n; s0 += bm.G * WOL_TRAJ_BLOCK) {
             const int s = s0 + tid;
@@ -173,7 +198,7 @@ k_cos_angs_traj(TrajShellArgs a) {
             if (live) {
                 const double4 v = sp[s];
                 c[0] = v.x; c[1] = v.y; c[2] = v.z;
-                wol_traj_candidates(g, sp, cs, a.n, c, [&](int slot, double d2) {
+                wol_traj_candidates(g, sp, cs, a.n, c, rint_ok, [&](int slot, double d2, const double4&) {
                     if (d2 > a.lowsq && d2 <= a.highsq) {
                         if (k < WOL_TRAJ_KMAX) my_slots[k * 64 + lane] = slot;
                         ++k;
@@ -246,16 +271,16 @@ __device__ __forceinline__ void wol_traj_angles_rewalk(const TrajShellArgs& a, c
     AngAcc acc = {0ull, 0ull, 0ll, 0ll, 0ll, 0ll};
     unsigned long long* __restrict__ gh = a.hist + (size_t)seg * a.nbins;
     int iu = 0;
-    wol_traj_candidates(g, sp, cs, a.n, c, [&](int su, double d2u) {
+    wol_traj_candidates(g, sp, cs, a.n, c, false, [&](int, double d2u, const double4& pu) {
         if (!(d2u > a.lowsq && d2u <= a.highsq)) return;
         double P1[3];
-        wol_traj_reimage(c, sp[su], g.box, P1);
+        wol_traj_reimage(c, pu, g.box, P1);
         int iv = 0;
-        wol_traj_candidates(g, sp, cs, a.n, c, [&](int sv, double d2v) {
+        wol_traj_candidates(g, sp, cs, a.n, c, false, [&](int, double d2v, const double4& pv) {
             if (!(d2v > a.lowsq && d2v <= a.highsq)) return;
             if (iv > iu) {
                 double P2[3];
-                wol_traj_reimage(c, sp[sv], g.box, P2);
+                wol_traj_reimage(c, pv, g.box, P2);
                 wol_traj_angle(wol_cos_angle3(P1, c, P2), a.nbins, nullptr, gh, acc);
             }
             ++iv;
@@ -315,7 +340,7 @@ k_cos_angs_traj_points(TrajShellArgs a) {
 // shell neighbours, or no next neighbour) contribute nothing.
 // stat[seg] = {len(lsiVals), sum LSI (hi, lo), sum LSI^2 (hi, lo), -, -, -}; hist[population][nbins] over [0, hist_max]
 // ---------------------------------------------------------------------------------------------
-#define WOL_TRAJ_LSI_ROW 20    // least doubles per lane in LDS: shell + next neighbour (a liquid's 3.7 A shell holds 4-9); the host
+#define WOL_TRAJ_LSI_ROW 16    // least doubles per lane in LDS: shell + next neighbour (a liquid's 3.7 A shell holds 4-9); the host
 #define WOL_TRAJ_LSI_ROWMAX 72 // sizes the rows for twice the shell the mean density predicts, up to this
 #define WOL_TRAJ_LSI_SLOWROW 1024
 
@@ -358,28 +383,40 @@ __device__ __forceinline__ double wol_traj_lsi_of_row(double* __restrict__ dist,
     return row_sum(true, mean) / (double)nd;
 }
 
-// shell walk of one query: distances into row[] (stride apart, at most cap - 1 of them), returns k (may exceed cap - 1)
-// and the next neighbour's minimum-image d2 (have_next)
+// shell walk of one query: the shell's minimum-image distances into row[] (stride apart, at most cap - 1 of them), returns k
+// (may exceed cap - 1) and the next neighbour's minimum-image d2 (have_next).  Inside the walk only squared distances are
+// handled: the square roots are taken once per kept distance afterwards, and the next neighbour -- the reference's argmin of
+// the RAW distances sqrt(sum (p - c)^2), first minimum in ascending original index -- is tracked by raw squared distance;
+// only where two squares are within a few ulp of each other (their roots could round to the same double, which the
+// reference would see as a tie) are the roots themselves compared.
 __device__ __forceinline__ int wol_traj_lsi_walk(const TrajShellArgs& a, const FrameGrid& g, const double4* __restrict__ sp,
                                                  const int* __restrict__ cs, const double c[3], double high2sq,
                                                  double* __restrict__ row, int stride, int cap, bool* have_next, double* next_d2) {
     int k = 0;
     bool hn = false;
-    double next_raw = 0.0, nd2 = 0.0;
+    double next_raw2 = 0.0, nd2 = 0.0;
     int next_idx = 0x7fffffff;
-    wol_traj_candidates(g, sp, cs, a.n, c, [&](int slot, double d2) {
+    wol_traj_candidates(g, sp, cs, a.n, c, wol_traj_rint_ok(g, a.reach), [&](int, double d2, const double4& p) {
         if (d2 > a.lowsq && d2 <= a.highsq) {
-            if (k < cap - 1) row[k * stride] = sqrt(d2);   // lsiDists, waterlib.f90:916
+            if (k < cap - 1) row[k * stride] = d2;
             ++k;
         }
         if (d2 > a.highsq && d2 <= high2sq) {
-            const double4 p = sp[slot];
             const double rx = p.x - c[0], ry = p.y - c[1], rz = p.z - c[2];
-            const double raw = sqrt(wol_sumsq(rx, ry, rz));
+            const double raw2 = wol_sumsq(rx, ry, rz);
             const int idx = (int)__double_as_longlong(p.w);
-            if (!hn || raw < next_raw || (raw == next_raw && idx < next_idx)) { hn = true; next_raw = raw; next_idx = idx; nd2 = d2; }
+            bool better;
+            if (!hn) better = true;
+            else if (fabs(raw2 - next_raw2) > 1e-15 * next_raw2) better = raw2 < next_raw2;
+            else {
+                const double ra = sqrt(raw2), rb = sqrt(next_raw2);
+                better = ra < rb || (ra == rb && idx < next_idx);
+            }
+            if (better) { hn = true; next_raw2 = raw2; next_idx = idx; nd2 = d2; }
         }
     });
+    const int kk = min(k, cap - 1);
+    for (int i = 0; i < kk; ++i) row[i * stride] = sqrt(row[i * stride]);   // lsiDists, waterlib.f90:916
     *have_next = hn;
     *next_d2 = nd2;
     return k;
