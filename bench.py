@@ -198,7 +198,9 @@ def main():
     distributed = world > 1 or ("LOCAL_RANK" in os.environ and "MASTER_PORT" in os.environ)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        import datetime
+        # (a rank that dies leaves its peers in a collective: they give up after five minutes instead of the default thirty)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=300))
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch N ranks with torch.distributed.run for --gpus N)"
                          % (args.gpus, world))
@@ -282,16 +284,36 @@ def main():
         run_job.local_s = local_done
         return out
 
-    if args.warmup > 0:
-        run_job(0, args.warmup)  # untimed: also loads every kernel the timed region uses
-    torch.cuda.synchronize()
+    def rank_failed(stage, exc):
+        """a rank that fails says so itself (its peers are left in a collective until the process group's timeout): one JSON
+        line on stderr with what it had measured, so a failed scaling run still shows which rank broke, where, and how far
+        it got"""
+        done = getattr(run_job, "local_s", None)
+        sys.stderr.write(json.dumps({"bench_rank_failed": {"rank": rank, "world": world, "stage": stage, "error": repr(exc)[:400],
+                                                            "frames_per_s_before_exchange": (args.steps * F / (done - t0)) if (done and stage == "timed") else None,
+                                                            "exchange_step_ms": exchange_ms[0]}}) + "\n")
+        sys.stderr.flush()
+
+    t0 = time.perf_counter()
+    try:
+        if args.warmup > 0:
+            run_job(0, args.warmup)  # untimed: also loads every kernel the timed region uses
+        torch.cuda.synchronize()
+    except Exception as e:
+        rank_failed("warmup", e)
+        raise
     ctx.kernel_time(reset=True)
+    run_job.local_s = None
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    total = run_job(args.warmup, args.steps)
-    torch.cuda.synchronize()
+    try:
+        total = run_job(args.warmup, args.steps)
+        torch.cuda.synchronize()
+    except Exception as e:
+        rank_failed("timed", e)
+        raise
     t_local = (getattr(run_job, "local_s", None) or time.perf_counter()) - t0   # this rank's own frames, before the exchange
     if distributed:
         dist.barrier()

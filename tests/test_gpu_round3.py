@@ -450,3 +450,39 @@ def test_tiled_pair_histogram_equals_the_walk_and_the_oracle(oracle):
     ctx.set_option("pair_tiled", 0)
     assert np.array_equal(g1, wl.radialdistsame(xyz[0], 0.1, 150, 1.0, boxes[0]))
     ctx.set_option("pair_tiled", 1)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 4, 5, 9, 13, 101])
+def test_soak_shell_trajectories_slice(seed):
+    """the trajectory generators of tools/soak_traj.py (NPT boxes, droplets, interleaved waters, float32 storage, frames
+    thousands of boxes from the origin) through wol_cos_angs_traj / wol_lsi_traj / wol_q_traj_pops against the per-frame
+    calls on the same frames: angle histograms and counts exact, per-water LSI bit for bit, population q bit for bit"""
+    from waterorderlib_amd import engine
+    from waterorderlib_amd import water_properties as wp
+    case = soak_gen.traj_case(seed, nmax=2500)
+    frames, boxes, len_wat, f32 = case["frames"][:6], case["boxes"][:6], case["len_wat"], case["f32"]
+    T = len(frames)
+    O = np.ascontiguousarray(frames[:, ::len_wat]).astype(np.float64)
+    rng = np.random.default_rng(seed)
+    sub = [O[t][rng.choice(O.shape[1], min(50, O.shape[1]), replace=False)] for t in range(T)]
+    pop_pos = np.concatenate(sub).astype(frames.dtype)
+    pop_off = np.concatenate([[0], np.cumsum([len(x) for x in sub])]).astype(np.int64)
+    ca = engine.cos_angs_traj(frames, boxes, len_wat=len_wat, pop_pos=pop_pos, pop_off=pop_off, npops=1)
+    ls = engine.lsi_traj(frames, boxes, len_wat=len_wat, want_lsi=True)
+    qp = engine.tet_order_traj_pops(frames, boxes, pop_pos, pop_off, 1, len_wat=len_wat, want_pop_q=True)
+    for t in range(T):
+        ang = wp.getCosAngs(O[t], O[t], boxes[t])[0]
+        assert np.array_equal(ca.hist[t, 0], _hist180(ang)) and ca.counts[t, 0, 0] == len(ang), (seed, t)
+        angp = wp.getCosAngs(sub[t].astype(frames.dtype).astype(np.float64), O[t], boxes[t])[0]
+        assert np.array_equal(ca.hist[t, 1], _hist180(angp)), (seed, t)
+        full = wp.getLSI(O[t], O[t], boxes[t], full=True)[0]
+        if f32:
+            np.testing.assert_allclose(ls.lsi[t].astype(np.float64), full, rtol=1e-6, atol=0, equal_nan=True)
+        else:
+            assert np.array_equal(ls.lsi[t], full, equal_nan=True), (seed, t)
+        q = wp.getOrderParamq(sub[t].astype(frames.dtype).astype(np.float64), O[t], boxes[t])
+        mine = qp.pop_q[pop_off[t]:pop_off[t + 1]]
+        if f32:
+            np.testing.assert_allclose(mine.astype(np.float64), q, rtol=0, atol=1e-6)
+        else:
+            assert np.array_equal(mine, q), (seed, t)
