@@ -486,3 +486,31 @@ def test_soak_shell_trajectories_slice(seed):
             np.testing.assert_allclose(mine.astype(np.float64), q, rtol=0, atol=1e-6)
         else:
             assert np.array_equal(mine, q), (seed, t)
+
+
+def test_trajectory_entries_reject_bad_arguments_and_take_odd_shapes():
+    """status codes, not crashes: population offsets that do not start at 0 / decrease / disagree with the points; NULL
+    frames; nbins out of range; T = 0; a histogram of 12 000 bins (more LDS than the default allows)"""
+    from waterorderlib_amd import _lib, engine, synth
+    L = _lib.load()
+    xyz, boxes = synth.water_frames(1500, 3, seed=4)
+    ctx = _lib.default_context()
+    pts = np.ascontiguousarray(xyz[:, :10].reshape(-1, 3))
+    good = np.arange(4, dtype=np.int64) * 10
+    hist = np.zeros((3, 2, 500), np.int64); cnt = np.zeros((3, 2, 2), np.int64); cs = np.zeros((3, 2, 2))
+    call = lambda off, nb=500, fr=xyz: L.wol_cos_angs_traj(ctx.handle, _lib.ptr(fr) if fr is not None else None, 3, 4500, 3, 1500, _lib.ptr(boxes), 0.0, 3.413,
+                                                           _lib.ptr(pts), _lib.ptr(off), 1, nb, _lib.ptr(hist), _lib.ptr(cnt), _lib.ptr(cs), 0, 0)
+    assert call(good) == 0
+    assert call(np.array([1, 10, 20, 30], dtype=np.int64)) == -1 and b"start at 0" in L.wol_last_error()
+    assert call(np.array([0, 20, 10, 30], dtype=np.int64)) == -1 and b"decrease" in L.wol_last_error()
+    assert call(good, nb=0) == -1 and call(good, nb=20000) == -1
+    assert call(good, fr=None) == -1
+    with pytest.raises(ValueError):
+        engine.cos_angs_traj(xyz, boxes, pop_pos=pts, pop_off=np.array([0, 10, 20, 31]), npops=1)
+    r = engine.cos_angs_traj(xyz[:0], boxes[:0])
+    assert r.hist.shape == (0, 1, 500)
+    big = engine.cos_angs_traj(xyz, boxes, nbins=12000)
+    ref = engine.cos_angs_traj(xyz, boxes, nbins=500)
+    assert np.array_equal(big.hist.reshape(3, 1, 500, 24).sum(-1), ref.hist) and np.array_equal(big.counts, ref.counts)
+    lr = engine.lsi_traj(xyz, boxes, nbins=3000, hist_max=0.6)
+    assert lr.hist.sum() <= lr.counts.sum() and lr.hist.shape == (1, 3000)

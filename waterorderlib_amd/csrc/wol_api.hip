@@ -125,6 +125,7 @@ struct wol_ctx {
                              // more (smaller frames sort faster through row buckets: their second read comes out of L2), 2 = whenever it applies, 0 = never
     int stages = 2;          // pipe depth of the trajectory path: 2 = sort | proposal + certification, 3 = sort | proposal | certification
     int search_margin = 0;   // blocks per CU the proposal / finish kernels leave free (room for an overlapped sort)
+    bool cos_traj_lds_set = false;
     bool skip_empty = true;         // the proposal kernel skips tile rows without any water (option "skip_empty_tiles")
     bool pair_tiled = true;         // RadialDistSame through the LDS-tiled pair kernel (option "pair_tiled"; 0 = the lane-per-water walk)
     bool check_props = false;       // diagnostic: poison the proposal arrays, count what the proposal kernel writes (k_check_props)
@@ -1609,6 +1610,10 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
         std::pair<hipEvent_t, hipEvent_t> ev;
         if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
         if (o.kind == 0) {
+            if (lds > 16 * 1024 && !c->cos_traj_lds_set) {   // (the kernel's own arrays take 40 KB: beyond 64 KB in all, say so)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cos_angs_traj), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+                c->cos_traj_lds_set = true;
+            }
             WOL_TRY(resident_grid(c, k_cos_angs_traj, WOL_TRAJ_BLOCK, lds, need, &grid));
             hipLaunchKernelGGL(k_cos_angs_traj, dim3(grid), dim3(WOL_TRAJ_BLOCK), lds, c->stream, ta);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
