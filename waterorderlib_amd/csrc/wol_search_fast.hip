@@ -751,19 +751,8 @@ k_finish_fast(FastArgs a) {
         const int64_t w = (int64_t)f * a.n + s;
         // key, proposal and own coordinates are fetched together (one round trip), the neighbours in a second one
         // (fetching the next 256 waters' share ahead of time was measured: no change, the gathers are what costs)
-#ifdef WOL_EXP_FINISH_NT
-        const int kd3 = live ? __builtin_nontemporal_load(&a.prop_key[w]) : 0;
-        int4 pr_all;
-        {
-            const int* pp = reinterpret_cast<const int*>(&a.prop[w]);
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(pp));
-            pr_all.x = t.x; pr_all.y = t.y; pr_all.z = t.z; pr_all.w = t.w;
-        }
-#else
         const int kd3 = live ? a.prop_key[w] : 0;
         const int4 pr_all = a.prop[w];
-#endif
         const double4 mev_all = sp[s];
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
