@@ -514,3 +514,30 @@ def test_trajectory_entries_reject_bad_arguments_and_take_odd_shapes():
     assert np.array_equal(big.hist.reshape(3, 1, 500, 24).sum(-1), ref.hist) and np.array_equal(big.counts, ref.counts)
     lr = engine.lsi_traj(xyz, boxes, nbins=3000, hist_max=0.6)
     assert lr.hist.sum() <= lr.counts.sum() and lr.hist.shape == (1, 3000)
+
+
+def test_long_thin_box_through_the_segment_sort(oracle):
+    """a slab-like box with hundreds of cell rows per layer and dozens of chunks per frame: the second sort level's LDS copy of
+    the row table outgrows the default dynamic-LDS limit (the launch used to fail there) -- the library
+    raises the kernel's limit or falls back to the row-bucket form; results equal the row-bucket form's and the oracle's"""
+    import torch
+    from waterorderlib_amd import _lib, engine
+    rng = np.random.default_rng(3)
+    box = np.array([120.0, 2600.0, 27.0])       # 577 cell rows per layer x 66 chunks: 76 KB of row table per block
+    n, T = 200000, 64
+    base = rng.random((n, 3)) * box
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    fr = (torch.from_numpy(base).cuda().unsqueeze(0) + 0.05 * torch.randn((T, n, 3), generator=g, device="cuda", dtype=torch.float64)).contiguous()
+    boxes = np.tile(box[None], (T, 1))
+    res = {}
+    for seg in (2, 0):
+        c = _lib.Context(0)
+        c.set_option("seg_sort", seg)
+        res[seg] = engine.tet_order_traj(fr, boxes, want_q=True, ctx=c)
+        torch.cuda.synchronize()
+        c.close()
+    assert torch.equal(res[2].qhist, res[0].qhist) and torch.equal(res[2].dhist, res[0].dhist)
+    assert torch.equal(res[2].mean, res[0].mean) and torch.equal(res[2].q, res[0].q)
+    pos = fr[5].cpu().numpy()
+    sample = rng.choice(n, 1500, replace=False)
+    np.testing.assert_allclose(res[2].q[5].cpu().numpy()[sample], oracle.getOrderParamq(pos[sample], pos, box, cells=True), rtol=0, atol=Q_TOL)
