@@ -276,6 +276,14 @@ int wol_lsi_traj(wol_ctx* ctx, const void* frames, int64_t atom_stride, int64_t 
                  int npops, int nbins, double hist_max, int64_t* lsi_hist, int64_t* counts, double* mean, double* var,
                  void* lsi_out, void* pop_lsi, int dtype, int mem);
 
+/* rdfCalc's frame loop for the water-water g(r) (orderParam_lib.py:624-630 calls wl.radialdistsame once per frame): per frame
+ * the pair counts of RadialDistSame (counts[T][totbins], bins ((k-1)w, k w], pairs once) and / or g(r) normalised exactly as
+ * wol_radial_dist_same does (rdf[T][totbins]; the caller sums frames in its own order, as the reference does).  Either
+ * output may be NULL.  Synchronises the stream (the normalisation is redone on the host from the integer counts). */
+int wol_radial_dist_same_traj(wol_ctx* ctx, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
+                              const double* boxes, double binwidth, int totbins, double bulkdens, double* rdf,
+                              int64_t* counts, int dtype, int mem);
+
 /* ---- multi-GPU: frame shards, one exchange step ------------------------------------------
  * The frame loop of tetOrderCalc has no dependence between frames (orderParam_lib.py:1458-1473): rank r of R (one
  * process per GPU) owns the contiguous block of frames given by wol_shard_bounds and runs the one-GPU pipeline on it;

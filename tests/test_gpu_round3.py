@@ -541,3 +541,28 @@ def test_long_thin_box_through_the_segment_sort(oracle):
     pos = fr[5].cpu().numpy()
     sample = rng.choice(n, 1500, replace=False)
     np.testing.assert_allclose(res[2].q[5].cpu().numpy()[sample], oracle.getOrderParamq(pos[sample], pos, box, cells=True), rtol=0, atol=Q_TOL)
+
+
+@pytest.mark.parametrize("form", ["host", "device", "f32"])
+def test_rdf_trajectory_equals_the_per_frame_calls(oracle, form):
+    """wol_radial_dist_same_traj: every frame's g(r) is wl.radialdistsame's for that frame, bit for bit (and the oracle's);
+    interleaved waters, a box per frame, a frame without a grid (non-periodic axis) in the middle"""
+    import torch
+    from waterorderlib_amd import engine, synth
+    from waterorderlib_amd import waterlib as wl
+    xyz, boxes = synth.water_frames(2500, 6, seed=21, len_wat=3)
+    boxes = boxes * (1.0 + 0.02 * np.arange(6))[:, None]
+    xyz = xyz * (1.0 + 0.02 * np.arange(6))[:, None, None]
+    boxes[3, 2] = -1.0                                   # frame 3: non-periodic along z
+    if form == "f32":
+        xyz = xyz.astype(np.float32)
+    fr = torch.from_numpy(xyz).cuda() if form == "device" else xyz
+    rdf, counts = engine.radial_dist_same_traj(fr, boxes, 0.1, 120, 1.0, len_wat=3, want_counts=True)
+    if form == "device":
+        rdf, counts = rdf.cpu().numpy(), counts.cpu().numpy()
+    for t in range(6):
+        O = np.ascontiguousarray(xyz[t, 0::3]).astype(np.float64)
+        ref = wl.radialdistsame(O, 0.1, 120, 1.0, boxes[t])
+        assert np.array_equal(rdf[t], ref), t
+        assert np.array_equal(ref, oracle.radialdistsame(O, 0.1, 120, 1.0, boxes[t])), t
+        assert counts[t].sum() > 0

@@ -27,7 +27,7 @@ SYMBOLS = ["wol_version", "wol_last_error", "wol_ctx_create", "wol_ctx_destroy",
            "wol_q_frame_t", "wol_cos_angs_t", "wol_lsi_frame_t",
            "wol_shard_bounds", "wol_comm_unique_id", "wol_comm_init", "wol_comm_adopt", "wol_comm_destroy",
            "wol_q_traj_sharded", "wol_q_traj_sharded_f32",
-           "wol_q_traj_pops", "wol_cos_angs_traj", "wol_lsi_traj"]
+           "wol_q_traj_pops", "wol_cos_angs_traj", "wol_lsi_traj", "wol_radial_dist_same_traj"]
 
 _lib = None
 
@@ -137,6 +137,8 @@ def load():
                                     C.c_int, _vp, _vp, _vp, C.c_int, C.c_int]
     L.wol_lsi_traj.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_double, _vp, _vp, C.c_int,
                                C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int]
+    L.wol_radial_dist_same_traj.argtypes = [_vp, _vp, C.c_int64, C.c_int64, C.c_int, C.c_int, _vp, C.c_double, C.c_int, C.c_double,
+                                            _vp, _vp, C.c_int, C.c_int]
     _lib = L
     return L
 

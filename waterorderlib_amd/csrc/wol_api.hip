@@ -1681,6 +1681,114 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
     return WOL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// rdfCalc's frame loop for the one-set g(r) (orderParam_lib.py:624-630: wl.radialdistsame per frame): batches through the
+// feeder and the sort stage (cells half the reach wide), one launch of the tiled pair kernel per frame, integer counts per
+// frame left on the device; the reference's normalisation is redone on the host from the counts, frame by frame.
+// ---------------------------------------------------------------------------------------------
+// rdf(k) = counts(k) / (NPos * BulkDens * (4./3.) * pi * binwidth**3 * (k**3 - (k-1)**3)) with the reference's
+// single-precision 4./3., truncated pi and integer k**3 (waterlib.f90:227-229, 353-355)
+void rdf_normalise(const std::vector<long long>& counts, int npos, double bulkdens, double binwidth, double* rdf) {
+    const double pi = 3.141592653589;
+    const double fourthirds = (double)(4.f / 3.f);
+    for (int k = 1; k <= (int)counts.size(); ++k) {
+        const int shell = k * k * k - (k - 1) * (k - 1) * (k - 1);
+        const double den = (double)npos * bulkdens * fourthirds * pi * (binwidth * binwidth * binwidth) * (double)shell;
+        rdf[k - 1] = (double)counts[(size_t)k - 1] / den;
+    }
+}
+
+
+template <typename T>
+int pair_hist_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_stride, int T_frames, int n, const double* boxes,
+                        double binwidth, int totbins, double bulkdens, double* rdf, int64_t* counts, int mem) {
+    WOL_TRY(check_ctx(c));
+    if (!frames || !boxes) return fail(WOL_ERR_INVALID, "frames/boxes must not be NULL");
+    if (T_frames < 0 || n <= 0) return fail(WOL_ERR_INVALID, "need T >= 0 and n > 0 (got T=%d n=%d)", T_frames, n);
+    if (atom_stride < 3) return fail(WOL_ERR_INVALID, "atom_stride must be >= 3");
+    if (frame_stride < (int64_t)(n - 1) * atom_stride + 3 && T_frames > 1) return fail(WOL_ERR_INVALID, "frame_stride smaller than one frame");
+    if (mem != WOL_MEM_HOST && mem != WOL_MEM_DEVICE) return fail(WOL_ERR_INVALID, "bad mem space");
+    if (!(binwidth > 0.0) || totbins <= 0 || totbins > 4000) return fail(WOL_ERR_INVALID, "rdf: need binwidth > 0 and 0 < totbins <= 4000");
+    if (rdf && totbins > 1290) return fail(WOL_ERR_INVALID, "rdf: totbins > 1290 overflows the reference's integer k**3");
+    if (T_frames == 0) return WOL_OK;
+    const bool host = (mem == WOL_MEM_HOST);
+    const double reach = binwidth * (double)totbins;
+    const double cell_w = reach < 5.0 ? reach * 1.001 : std::fmax(reach * 0.5, 2.5);
+    FrameFeeder<T> feed;
+    WOL_TRY(feed.plan(c, frames, atom_stride, frame_stride, T_frames, n, host, 96.0));
+    const size_t hb = sizeof(unsigned long long) * (size_t)T_frames * totbins;
+    WOL_TRY(c->pop_hist.ensure(hb));
+    HIP_TRY(hipMemsetAsync(c->pop_hist.p, 0, hb, c->stream));
+    const size_t lds = sizeof(int) * (size_t)totbins;
+    WOL_TRY(feed.start());
+    for (int b = 0; b < feed.nbatch; ++b) {
+        const int f0 = feed.bstart[b], F = feed.bstart[b + 1] - f0;
+        FrameBatchView bv;
+        WOL_TRY(feed.acquire(b, &bv));
+        BatchPlan bp;
+        if (bv.f32) WOL_TRY(sort_batch<float>(c, view_as<float>(bv, n), F, boxes + 3 * (size_t)f0, cell_w, reach, false, false, 0, &bp, true));
+        else WOL_TRY(sort_batch<double>(c, view_as<double>(bv, n), F, boxes + 3 * (size_t)f0, cell_w, reach, false, false, 0, &bp, true));
+        wol_ctx::SortSet& S = *bp.S;
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
+        for (int f = 0; f < F; ++f) {
+            const FrameGrid* gh = bp.gh + f;
+            unsigned long long* hist = c->pop_hist.as<unsigned long long>() + (size_t)(f0 + f) * totbins;
+            int grid = 0;
+            if (gh->maxshell >= 0 && c->pair_tiled && reach < 60.0) {
+                PairTileArgs pa;
+                pa.grid = S.grids.as<FrameGrid>() + f; pa.sorted = S.sorted.as<double4>() + (size_t)f * n; pa.cell_start = S.cells.as<int>(); pa.n = n;
+                const double wpc = std::fmax((double)n / (double)gh->ncell, 0.05);
+                int cxrun = std::min((int)std::fmax(1.0, std::floor(58.0 / wpc)), gh->nc[0]);
+                pa.ntx = (gh->nc[0] + cxrun - 1) / cxrun;
+                pa.cxrun = (gh->nc[0] + pa.ntx - 1) / pa.ntx;
+                pa.need_minimg = 0;
+                const double ext[3] = {0.5 * pa.cxrun * gh->cw[0], 0.5 * gh->cw[1], 0.5 * gh->cw[2]};
+                for (int k = 0; k < 3; ++k)
+                    if (gh->box.L[k] < 2.0 * (ext[k] + reach) + 1.0) pa.need_minimg = 1;
+                pa.binwidth = binwidth; pa.totbins = totbins;
+                pa.cut2f = (float)(reach * reach * (1.0 + 1e-5) + 1e-3);
+                pa.hist = hist;
+                const int64_t units = (int64_t)gh->nc[1] * gh->nc[2] * pa.ntx * (gh->lo[1] + gh->hi[1] + 1) * (gh->lo[2] + gh->hi[2] + 1);
+                if (pa.need_minimg) {
+                    WOL_TRY(resident_grid(c, k_pair_hist_tiled<true>, WOL_PT_BLOCK, lds, units, &grid));
+                    hipLaunchKernelGGL(k_pair_hist_tiled<true>, dim3(grid), dim3(WOL_PT_BLOCK), lds, c->stream, pa);
+                } else {
+                    WOL_TRY(resident_grid(c, k_pair_hist_tiled<false>, WOL_PT_BLOCK, lds, units, &grid));
+                    hipLaunchKernelGGL(k_pair_hist_tiled<false>, dim3(grid), dim3(WOL_PT_BLOCK), lds, c->stream, pa);
+                }
+            } else {
+                ShellArgs sa;
+                sa.grid = S.grids.as<FrameGrid>() + f; sa.sorted = S.sorted.as<double4>() + (size_t)f * n; sa.cell_start = S.cells.as<int>();
+                sa.n = n; sa.sub = nullptr; sa.ns = n; sa.use_cells = gh->maxshell >= 0 ? 1 : 0; sa.lowsq = 0.0; sa.highsq = 0.0;
+                WOL_TRY(resident_grid(c, k_pair_hist, WOL_BLOCK, lds, (n + WOL_BLOCK - 1) / WOL_BLOCK, &grid));
+                hipLaunchKernelGGL(k_pair_hist, dim3(grid), dim3(WOL_BLOCK), lds, c->stream, sa, 1, binwidth, totbins, hist);
+            }
+        }
+        if (c->time_kernels) WOL_TRY(end_timing(c, ev));
+        HIP_TRY(hipEventRecord(S.free_ev, c->stream));
+        S.used = true;
+        WOL_TRY(feed.release(b));
+    }
+    std::vector<long long> hc((size_t)T_frames * totbins);
+    HIP_TRY(hipMemcpyAsync(hc.data(), c->pop_hist.p, hb, hipMemcpyDeviceToHost, c->stream));
+    if (counts && !host) HIP_TRY(hipMemcpyAsync(counts, c->pop_hist.p, hb, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    if (counts && host) memcpy(counts, hc.data(), hb);
+    if (rdf) {
+        std::vector<double> r((size_t)T_frames * totbins);
+        std::vector<long long> one((size_t)totbins);
+        for (int t = 0; t < T_frames; ++t) {
+            std::copy(hc.begin() + (size_t)t * totbins, hc.begin() + (size_t)(t + 1) * totbins, one.begin());
+            rdf_normalise(one, n, bulkdens, binwidth, r.data() + (size_t)t * totbins);
+        }
+        if (host) memcpy(rdf, r.data(), sizeof(double) * r.size());
+        else HIP_TRY(hipMemcpy(rdf, r.data(), sizeof(double) * r.size(), hipMemcpyHostToDevice));
+    }
+    return WOL_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -2346,18 +2454,6 @@ static int pair_counts_impl(wol_ctx* c, const double* pos1, int n1, const double
     return WOL_OK;
 }
 
-// rdf(k) = counts(k) / (NPos * BulkDens * (4./3.) * pi * binwidth**3 * (k**3 - (k-1)**3)) with the reference's
-// single-precision 4./3., truncated pi and integer k**3 (waterlib.f90:227-229, 353-355)
-static void rdf_normalise(const std::vector<long long>& counts, int npos, double bulkdens, double binwidth, double* rdf) {
-    const double pi = 3.141592653589;
-    const double fourthirds = (double)(4.f / 3.f);
-    for (int k = 1; k <= (int)counts.size(); ++k) {
-        const int shell = k * k * k - (k - 1) * (k - 1) * (k - 1);
-        const double den = (double)npos * bulkdens * fourthirds * pi * (binwidth * binwidth * binwidth) * (double)shell;
-        rdf[k - 1] = (double)counts[(size_t)k - 1] / den;
-    }
-}
-
 int wol_radial_dist_same(wol_ctx* c, const double* pos, int n, double binwidth, int totbins, double bulkdens,
                          const double* box, double* rdf) {
     if (!rdf) return fail(WOL_ERR_INVALID, "rdf: output must not be NULL");
@@ -2534,6 +2630,16 @@ int wol_cos_angs_traj(wol_ctx* c, const void* frames, int64_t atom_stride, int64
     if (dtype == WOL_F64)
         return shell_traj_impl<double>(c, static_cast<const double*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, pq, o, mem);
     return shell_traj_impl<float>(c, static_cast<const float*>(frames), atom_stride, frame_stride, T, n, boxes, lowcut, highcut, pq, o, mem);
+}
+
+int wol_radial_dist_same_traj(wol_ctx* c, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n, const double* boxes,
+                              double binwidth, int totbins, double bulkdens, double* rdf, int64_t* counts, int dtype, int mem) {
+    WOL_TRY(check_real(dtype, mem));
+    if (dtype == WOL_F64)
+        return pair_hist_traj_impl<double>(c, static_cast<const double*>(frames), atom_stride, frame_stride, T, n, boxes, binwidth, totbins,
+                                           bulkdens, rdf, counts, mem);
+    return pair_hist_traj_impl<float>(c, static_cast<const float*>(frames), atom_stride, frame_stride, T, n, boxes, binwidth, totbins, bulkdens,
+                                      rdf, counts, mem);
 }
 
 int wol_lsi_traj(wol_ctx* c, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n, const double* boxes,

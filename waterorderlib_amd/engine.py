@@ -374,3 +374,15 @@ def lsi_traj(frames, boxes, lowCut=0.0, highCut=3.7, len_wat=1, pop_pos=None, po
                                             float(highCut), fr.p(pts), _lib.ptr(off), npops, nbins, float(hist_max), fr.p(hist), fr.p(counts),
                                             fr.p(mean), fr.p(var), fr.p(lsi), fr.p(plsi), fr.dtype, fr.mem))
     return LsiTrajResult(hist, counts, mean, var, lsi, plsi)
+
+
+def radial_dist_same_traj(frames, boxes, binwidth=0.1, totbins=150, bulkdens=1.0, len_wat=1, want_counts=False, ctx=None):
+    """rdfCalc's per-frame wl.radialdistsame (orderParam_lib.py:624-630) for a block of frames in one call: rdf[T, totbins]
+    (each row what wl.radialdistsame returns for that frame, bit for bit) and, when asked for, the integer pair counts."""
+    fr = _Frames(frames, boxes, len_wat, ctx)
+    rdf = fr.empty((fr.T, totbins), "f64", True)
+    counts = fr.empty((fr.T, totbins), "i64", True) if want_counts else None
+    if fr.T and fr.n:
+        _lib.check(_lib.load().wol_radial_dist_same_traj(fr.ctx.handle, fr.ptr, 3 * len_wat, 3 * fr.natoms, fr.T, fr.n, _lib.ptr(fr.boxes),
+                                                         float(binwidth), int(totbins), float(bulkdens), fr.p(rdf), fr.p(counts), fr.dtype, fr.mem))
+    return (rdf, counts) if want_counts else rdf

@@ -260,12 +260,16 @@ def rdfCalc(topFile, trajFile=None, solResName='(!:WAT)', watResName='(:WAT)', b
     tot = {k: [] for k in ("OwOw", "SolOw", "SolSol")}
     totc = {k: [] for k in ("OwOw", "SolOw", "SolSol")}
     tot_n1_OwOw, tot_n1_SolOw, tot_tParam = [], [], []
+    # the water-water g(r) of every frame the five chunks use, in one trajectory call (wol_radial_dist_same_traj): row f is what
+    # wl.radialdistsame returns for frame f; the sums below run in the reference's order
+    nUsed = nChunks * chunkSize
+    owow = engine.radial_dist_same_traj(np.stack([xyz[f][watInds] for f in range(nUsed)]), boxes[:nUsed], binwidth, totbins, 1.0)
     for c in range(nChunks):
         rdf = {k: np.zeros(totbins) for k in tot}
         t = 0
         for t, f in enumerate(range(int(c * chunkSize), int((c + 1) * chunkSize))):
             thisWat = np.ascontiguousarray(xyz[f][watInds])
-            rdf["OwOw"] = rdf["OwOw"] + wl.radialdistsame(thisWat, binwidth, totbins, 1.0, boxes[f])
+            rdf["OwOw"] = rdf["OwOw"] + owow[f]
             if has_sol:
                 thisSol = np.ascontiguousarray(xyz[f][solInds])
                 rdf["SolSol"] = rdf["SolSol"] + wl.radialdistsame(thisSol, binwidth, totbins, 1.0, boxes[f])
