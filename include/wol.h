@@ -268,9 +268,9 @@ int wol_cos_angs_traj(wol_ctx* ctx, const void* frames, int64_t atom_stride, int
  * all frames, ACCUMULATED (the reference: 500 bins over [0, 0.3]).  Optional: lsi_out[T][n] = LSI of every water in the
  * caller's water order (NaN where the reference skips it), pop_lsi[total] likewise for the population points.
  * The kernel keeps a water's shell in LDS rows sized for twice what the mean density predicts; denser shells (clusters) are
- * finished from rows in global memory.  A shell of more than 1022 waters, or more than max(4096, waters per batch / 16)
- * such waters in one batch, is reported as WOL_ERR_INVALID: use wol_lsi_frame for such inputs.  Both shell trajectory calls synchronise the stream once, at the
- * end, to report that condition. */
+ * finished from rows in global memory, however many waters of a batch that takes.  A shell of more than 1022 waters is
+ * reported as WOL_ERR_INVALID: use wol_lsi_frame for such inputs.  Both shell trajectory calls synchronise the stream
+ * once, at the end, to report that condition. */
 int wol_lsi_traj(wol_ctx* ctx, const void* frames, int64_t atom_stride, int64_t frame_stride, int T, int n,
                  const double* boxes, double lowcut, double highcut, const void* pop_pos, const int64_t* pop_off,
                  int npops, int nbins, double hist_max, int64_t* lsi_hist, int64_t* counts, double* mean, double* var,

@@ -360,6 +360,18 @@ def test_lsi_traj_with_shells_of_dozens_and_hundreds_of_waters():
     for t in range(2):
         full = wp.getLSI(pos[t], pos[t], bx, full=True)[0]
         assert np.array_equal(res.lsi[t], full, equal_nan=True)
+    # a droplet in every frame: more dense shells in one batch (6 x 1000) than any fixed list would hold, population points
+    # inside the droplet as well (found by tools/soak_shell_traj.py, seed 49)
+    T = 6
+    pos = rng.random((T, 4000, 3)) * bx
+    pos[:, :1000] = bx * 0.5 + rng.normal(0.0, 3.0, size=(T, 1000, 3))
+    pts = np.ascontiguousarray(pos[:, 900:1100]).reshape(-1, 3)
+    off = np.arange(T + 1, dtype=np.int64) * 200
+    res = engine.lsi_traj(pos, np.tile(bx[None], (T, 1)), pop_pos=pts, pop_off=off, npops=1, want_lsi=True, want_pop_lsi=True)
+    for t in range(T):
+        full = wp.getLSI(pos[t], pos[t], bx, full=True)[0]
+        assert np.array_equal(res.lsi[t], full, equal_nan=True)
+        assert np.array_equal(res.pop_lsi[off[t]:off[t + 1]], full[900:1100], equal_nan=True)
 
 
 @pytest.mark.parametrize("form", ["host", "device", "f32"])

@@ -1552,14 +1552,19 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
     HIP_TRY(hipMemsetAsync(c->pop_stat.p, 0, stat_b, c->stream));
     HIP_TRY(hipMemsetAsync(c->pop_hist.p, 0, sizeof(unsigned long long) * hist_n, c->stream));
     // waters whose shell outgrows the kernels' LDS rows are listed and finished by the slow kernels: the three-body one
-    // recomputes (no storage: every water may be listed), the LSI one keeps rows of WOL_TRAJ_LSI_SLOWROW doubles in global memory
+    // recomputes, the LSI one keeps one row of WOL_TRAJ_LSI_SLOWROW doubles per lane of its grid in global memory: no storage
+    // per listed water, so every water (and, for the LSI, every population point) of a batch may be listed
     const int64_t batch_waters = (int64_t)feed.Fb * n;
-    const int slow_cap = o.kind == 0 ? (int)std::min<int64_t>(batch_waters, 1 << 30)
-                                     : (int)std::min<int64_t>(std::max<int64_t>(4096, batch_waters / 16), 32768);
+    int64_t batch_pts = 0;
+    if (o.kind == 1 && npops > 0)
+        for (int b = 0; b < nbatch; ++b)
+            batch_pts = std::max<int64_t>(batch_pts, pq.off[(size_t)feed.bstart[b + 1] * npops] - pq.off[(size_t)feed.bstart[b] * npops]);
+    const int slow_cap = (int)std::min<int64_t>(batch_waters + batch_pts, 1 << 30);
+    const int slow_grid = 16;
     WOL_TRY(c->slow_list.ensure(sizeof(unsigned long long) * (size_t)slow_cap));
     WOL_TRY(c->slow_count.ensure(sizeof(int) * 4));
     HIP_TRY(hipMemsetAsync(c->slow_count.p, 0, sizeof(int) * 4, c->stream));
-    if (o.kind == 1) WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)slow_cap * WOL_TRAJ_LSI_SLOWROW));
+    if (o.kind == 1) WOL_TRY(c->qbuf.ensure(sizeof(double) * (size_t)slow_grid * WOL_TRAJ_BLOCK * WOL_TRAJ_LSI_SLOWROW));
     if (o.per_point && npts > 0) WOL_TRY(c->pop_out.ensure(sizeof(double) * (size_t)npts));
     const bool pw_direct = o.per_water && !host && dtype == WOL_F64;
     // cells as wide as the reach (27-cell walk) for short reaches, half the reach (125 cells) for long ones
@@ -1617,7 +1622,7 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
             WOL_TRY(resident_grid(c, k_cos_angs_traj, WOL_TRAJ_BLOCK, lds, need, &grid));
             hipLaunchKernelGGL(k_cos_angs_traj, dim3(grid), dim3(WOL_TRAJ_BLOCK), lds, c->stream, ta);
             if (c->time_kernels) WOL_TRY(end_timing(c, ev));
-            hipLaunchKernelGGL(k_cos_angs_traj_slow, dim3(16), dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta);
+            hipLaunchKernelGGL(k_cos_angs_traj_slow, dim3(slow_grid), dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta);
             if (pts_here > 0)
                 hipLaunchKernelGGL(k_cos_angs_traj_points, dim3((unsigned)std::min<int64_t>((pts_here + WOL_TRAJ_BLOCK - 1) / WOL_TRAJ_BLOCK, 4096)),
                                    dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta);
@@ -1636,7 +1641,7 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
             if (pts_here > 0)
                 hipLaunchKernelGGL(k_lsi_traj_points, dim3((unsigned)std::min<int64_t>((pts_here + WOL_TRAJ_BLOCK - 1) / WOL_TRAJ_BLOCK, 4096)),
                                    dim3(WOL_TRAJ_BLOCK), rows_lds, c->stream, ta, high2 * high2, lsi_row, ptq);
-            hipLaunchKernelGGL(k_lsi_traj_slow, dim3(16), dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta, high2 * high2, c->qbuf.as<double>(), ptq);
+            hipLaunchKernelGGL(k_lsi_traj_slow, dim3(slow_grid), dim3(WOL_TRAJ_BLOCK), 0, c->stream, ta, high2 * high2, c->qbuf.as<double>(), ptq);
         }
         HIP_TRY(hipEventRecord(S.free_ev, c->stream));
         S.used = true;
@@ -1676,7 +1681,7 @@ int shell_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t fr
         for (size_t k = 0; k < hist_n; ++k) o.hist[k] += (int64_t)h[k];
     }
     HIP_TRY(hipGetLastError());
-    if (flags[1] == 1) return fail(WOL_ERR_INVALID, "more than %d waters of a batch have shells denser than the trajectory form's rows (%d); use the per-frame call", slow_cap, lsi_row - 2);
+    if (flags[1] == 1) return fail(WOL_ERR_INVALID, "the list of dense shells overflowed (%d entries)", slow_cap);
     if (flags[1] == 2) return fail(WOL_ERR_INVALID, "a shell holds more than %d waters; use the per-frame call", WOL_TRAJ_LSI_SLOWROW - 2);
     return WOL_OK;
 }

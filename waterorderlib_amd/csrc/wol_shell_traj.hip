@@ -528,8 +528,9 @@ k_lsi_traj_points(TrajShellArgs a, double high2sq, int row_len, double* __restri
     }
 }
 
-// queries whose shell outgrew the LDS row (waters: frame << 32 | slot; population points: bit 63 | point): rows of
-// WOL_TRAJ_LSI_SLOWROW doubles in global scratch, one lane per query
+// queries whose shell outgrew the LDS row (waters: frame << 32 | slot; population points: bit 63 | point): one lane per
+// query, each lane of the grid owning one row of WOL_TRAJ_LSI_SLOWROW doubles in global scratch (so the list may hold every
+// water of the batch: a droplet far denser than the box's mean puts thousands there)
 __global__ void __launch_bounds__(WOL_TRAJ_BLOCK)
 k_lsi_traj_slow(TrajShellArgs a, double high2sq, double* __restrict__ scratch, double* __restrict__ pt_out) {
     const int count = min(*a.slow_count, a.slow_cap);
@@ -554,7 +555,7 @@ k_lsi_traj_slow(TrajShellArgs a, double high2sq, double* __restrict__ scratch, d
             seg = (a.f0 + f) * (a.npops + 1);
         }
         const FrameGrid& g = a.grids[f];
-        double* __restrict__ row = scratch + (size_t)i * WOL_TRAJ_LSI_SLOWROW;
+        double* __restrict__ row = scratch + (size_t)(blockIdx.x * WOL_TRAJ_BLOCK + threadIdx.x) * WOL_TRAJ_LSI_SLOWROW;
         bool have_next;
         double next_d2;
         const int k = wol_traj_lsi_walk(a, g, a.sorted + (int64_t)f * a.n, a.cell_start + g.cell_base, c, high2sq, row, 1,
