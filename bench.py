@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--stages", type=int, default=-1, help="pipe depth of the overlapped trajectory path (2 / 3)")
     ap.add_argument("--want-q", action="store_true", help="also write per-water q (8 B per water more per step)")
     ap.add_argument("--rows-block", type=int, default=-1, help="force the proposal kernel's instantiation (512 / 768)")
+    ap.add_argument("--rec32", type=int, default=-1, help="float32 frames: 1 = 16-byte sorted records (library default), 0 = 32-byte")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-memory (PCIe-inclusive) leg")
     ap.add_argument("--e2e-frames", type=int, default=192, help="host frames of the end-to-end leg")
     args = ap.parse_args()
@@ -254,6 +255,8 @@ def main():
         ctx.set_option("dyn_tiles", args.dyn_tiles)
     if args.rows_block >= 0:
         ctx.set_option("rows_block", args.rows_block)
+    if args.rec32 >= 0:
+        ctx.set_option("rec32", args.rec32)
 
     total_steps = args.warmup + args.steps
     # every step owns its frames; generated (untimed) up front so the timed region only reads HBM

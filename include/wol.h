@@ -81,7 +81,10 @@ int wol_ctx_synchronize(wol_ctx* ctx);
  * interleaved frames, one linear copy per batch; 1 = the O rows only, packed by host threads into pinned staging -- what
  * the reference's caller does with pos[watInds], orderParam_lib.py:1462; 2 = the same, as float32 whenever every coordinate
  * of the batch is exactly a float32 -- bit-identical results at half the bytes; default 2), "host_threads" (packing
- * threads, 0 = min(16, hardware threads)) */
+ * threads, 0 = min(16, hardware threads)), "rec32" (1 = float32 frames of the trajectory q calls keep their values as
+ * 16-byte (x, y, z, index) float records through both sort levels and in the certification kernel's gathers, promoted
+ * exactly where the fp64 arithmetic starts -- bit-identical results, half the sort's bytes; default; 0 = 32-byte double
+ * records as for float64 frames) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
@@ -92,6 +95,7 @@ int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int r
  * "density_level" = tile-shape level the device picked for frame 0 (0 = box-average density);
  * "rows_block" = threads per block of the k_search_rows instantiation that ran (0: another proposal kernel);
  * "h2d_bytes" = bytes the last host-memory trajectory call sent over the host link;
+ * "record_bytes" = size of a sorted record in the last q batch (32; 16 for float32 frames, option "rec32");
  * "proposals_written" / "proposals_expected" / "proposals_bad": see option "check_proposals" (accumulated, not per call) */
 int wol_ctx_get_counter(wol_ctx* ctx, const char* key, int64_t* value);
 

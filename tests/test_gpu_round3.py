@@ -578,3 +578,55 @@ def test_rdf_trajectory_equals_the_per_frame_calls(oracle, form):
         assert np.array_equal(rdf[t], ref), t
         assert np.array_equal(ref, oracle.radialdistsame(O, 0.1, 120, 1.0, boxes[t])), t
         assert counts[t].sum() > 0
+
+
+@pytest.mark.parametrize("shape", ["many_small", "few_big", "interleaved", "long_rows", "thin_box", "host"])
+def test_float32_frames_keep_16_byte_records_bit_for_bit(shape):
+    """float32 frames go through both sort levels and the certification kernel's gathers as 16-byte (x, y, z, index)
+    records (option rec32, default) -- on every form of the first sort level (one block per frame: segments and row buckets;
+    frames split over blocks; tables of thousands of rows; rows of hundreds of waters) the per-water q, the per-frame
+    statistics and both integer histograms equal those of the 32-byte records AND those of the same frames promoted to
+    float64 on the caller's side, bit for bit."""
+    import torch
+    from waterorderlib_amd import engine, synth, _lib
+    rng = np.random.default_rng(17)
+    if shape == "many_small":
+        xyz, boxes = synth.water_frames(3000, 96, seed=3)              # one block per frame, row buckets
+    elif shape == "few_big":
+        xyz, boxes = synth.water_frames(120000, 4, seed=4)             # frames split over blocks (count / scan / scatter)
+    elif shape == "interleaved":
+        xyz, boxes = synth.water_frames(30000, 64, seed=5)             # one block per frame, segment form
+    elif shape == "long_rows":
+        bx = np.array([400.0, 21.0, 21.0])                             # 25 rows of ~240 waters: four waters per lane in a row
+        xyz = (rng.random((64, 6000, 3)) * bx); boxes = np.tile(bx[None], (64, 1))
+    elif shape == "thin_box":
+        bx = np.array([21.0, 50.0, 1700.0])                            # 4 444 short rows: the first level's big row tables
+        xyz = (rng.random((8, 60000, 3)) * bx); boxes = np.tile(bx[None], (8, 1))
+    else:
+        xyz, boxes = synth.water_frames(20000, 70, seed=6)
+    f32 = np.ascontiguousarray(xyz.astype(np.float32))
+    if shape == "interleaved":                                         # TIP4P-like: the oxygens are every fourth atom
+        full = np.full((f32.shape[0], f32.shape[1] * 4, 3), 1.0e6, np.float32)
+        full[:, ::4] = f32
+        f32, len_wat = full, 4
+    else:
+        len_wat = 1
+    ctx = _lib.Context()
+    dev = (lambda a: a) if shape == "host" else (lambda a: torch.as_tensor(a, device="cuda"))
+    out = {}
+    for rec in (1, 0):
+        ctx.set_option("rec32", rec)
+        r = engine.tet_order_traj(dev(f32), boxes, len_wat=len_wat, want_q=True, ctx=ctx)
+        torch.cuda.synchronize()
+        assert ctx.counter("record_bytes") == (16 if rec else 32)
+        out[rec] = [np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (r.mean, r.var, r.qhist, r.dhist, r.q)]
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b)
+    wide = np.ascontiguousarray(f32[:, ::len_wat].astype(np.float64))
+    r64 = engine.tet_order_traj(dev(wide), boxes, want_q=True, ctx=ctx)
+    torch.cuda.synchronize()
+    ref = [np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (r64.mean, r64.var, r64.qhist, r64.dhist)]
+    for a, b in zip(out[1][:4], ref):
+        assert np.array_equal(a, b)
+    q64 = np.asarray(r64.q.cpu() if hasattr(r64.q, "cpu") else r64.q)
+    assert np.array_equal(out[1][4], q64.astype(np.float32))

@@ -116,8 +116,10 @@ struct wol_ctx {
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
     size_t sort_rows_lds_set = 0;
-    size_t in_row_static_lds[2] = {0, 0}, in_row_dyn_limit[2] = {0, 0};   // k_sort_in_row<2> / <4>: static LDS, dynamic LDS allowed so far
+    size_t in_row_static_lds[4] = {0, 0, 0, 0}, in_row_dyn_limit[4] = {0, 0, 0, 0};   // k_sort_in_row<2> / <4> (+ 2: float4 records): static LDS, dynamic LDS allowed so far
+    int rec32 = 1;           // float32 frames keep 16-byte records through the sort and the certification (option "rec32"; 0 = promote in the first level)
     int last_rows_block = 0;
+    int last_rec_bytes = 0;
     int force_rows_block = 0;  // 0 = per batch by lane fill; 512 / 768 = that k_search_rows instantiation (tests, tuning)
     int sort_parts = 0;      // > 0: blocks per frame of the streaming sort's first level (0 = automatic)
     int dyn_tiles = 1;       // 1: the proposal kernel's blocks draw their tiles from per-XCD counters (default); 0: static tile order
@@ -472,6 +474,7 @@ struct BatchPlan {
     int n_cell_frames = 0;
     std::vector<int> brute_frames;     // frames without a grid (non-periodic axis, tiny inputs, forced): all-pairs kernels
     bool use_fast = false, rows_kernel = false, level_early = false, pipe = false;
+    bool rec32 = false;                // the sorted records are float4 (float32 frames through the streaming sort: wol_rec)
     int rows_block = 0, tiles_max = 0, tile_any_stride = 0;
     float4* s32 = nullptr;
     unsigned* cnt4 = nullptr;
@@ -484,7 +487,7 @@ struct BatchPlan {
 // bp->S holds cell-sorted fp64 records (sorted), cell_start (cells) and the grids on the device.
 template <typename T>
 int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, double cell_width, double reach,
-               bool want_fast, bool force_brute, int allow_pipe, BatchPlan* bp, bool need_set = false) {
+               bool want_fast, bool force_brute, int allow_pipe, BatchPlan* bp, bool need_set = false, bool want_rec32 = false) {
     const int n = fv.n;
 
     // --- per-frame grids (host) ---
@@ -605,6 +608,11 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
             nrow_max = std::max(nrow_max, gh[f].nc[1] * gh[f].nc[2]);
         }
         const bool big_rows = nrow_max > WOL_L1_MAXROWS;
+        // float32 frames on their way to the row-merged q pipeline keep their single-precision values through both sort levels
+        // (16-byte records: half the sort's traffic, half the bytes of the certification kernel's gathers); every other consumer
+        // of a sorted set reads double4 records
+        const bool rec32 = want_rec32 && std::is_same<T, float>::value && layer_sort && use_fast && rows_kernel && !pipe && c->rec32;
+        const size_t rec_size = rec32 ? sizeof(float4) : sizeof(double4);
         // second level of every sort: the rows (cell-sorted or merely bucketed) are sorted by fine x bin, with the bin
         // populations per cell, into the final arrays.  The row-merged proposal kernel stages from rows in that order.
         const bool in_row_stage = layer_sort || (use_fast && rows_kernel);
@@ -632,9 +640,10 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         // does it fit next to the kernel's static arrays?  (raises the kernel's dynamic-LDS limit when it has to: a long thin
         // box has hundreds of rows per layer and a hundred chunks)
         auto in_row_fits = [&](size_t dyn) -> bool {
-            const void* fn = in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4>) : reinterpret_cast<const void*>(&k_sort_in_row<2>);
-            size_t& stat = c->in_row_static_lds[in_row_long ? 1 : 0];
-            size_t& limit = c->in_row_dyn_limit[in_row_long ? 1 : 0];
+            const void* fn = rec32 ? (in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4, float4>) : reinterpret_cast<const void*>(&k_sort_in_row<2, float4>))
+                                   : (in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4>) : reinterpret_cast<const void*>(&k_sort_in_row<2>));
+            size_t& stat = c->in_row_static_lds[(in_row_long ? 1 : 0) + (rec32 ? 2 : 0)];
+            size_t& limit = c->in_row_dyn_limit[(in_row_long ? 1 : 0) + (rec32 ? 2 : 0)];
             if (!stat) {
                 hipFuncAttributes fa_;
                 if (hipFuncGetAttributes(&fa_, fn) != hipSuccess) return false;
@@ -653,7 +662,15 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         };
         auto launch_in_row = [&](int ro_stride) {
             const size_t lds = in_row_lds(pieces.tab ? pieces.nchunk_cap : 0, pieces.ny_cap);
-            if (in_row_long)
+            if (rec32 && in_row_long)
+                hipLaunchKernelGGL((k_sort_in_row<4, float4>), dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<float4>(), s32, cnt4, nb_cap, pieces);
+            else if (rec32)
+                hipLaunchKernelGGL((k_sort_in_row<2, float4>), dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<float4>(), s32, cnt4, nb_cap, pieces);
+            else if (in_row_long)
                 hipLaunchKernelGGL(k_sort_in_row<4>, dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
                                    c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), n, S.cells.as<int>(),
                                    S.sorted.as<double4>(), s32, cnt4, nb_cap, pieces);
@@ -699,6 +716,10 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 c->sort_rows_lds_set = 1;
             }
             if (P == 1 && pipe) {
@@ -714,10 +735,25 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 const int chunk_waters = WOL_L1_CHUNK * WOL_SORT_BLOCK, nchunk = (n + chunk_waters - 1) / chunk_waters;
                 WOL_TRY(c->seg_tab.ensure(sizeof(unsigned short) * (size_t)F * (size_t)(nrow_max + 1) * nchunk));
                 pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all_frames + 1};
+                if constexpr (std::is_same<T, float>::value) {
+                    if (rec32)
+                        hipLaunchKernelGGL((k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(F), dim3(WOL_SORT_BLOCK),
+                                           wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK, WOL_SORT_BLOCK, rec_size), ss, fv,
+                                           S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
+                                           c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);
+                }
+                if (!rec32)
                 hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
                                    c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);
             } else if (P == 1) {
+                if constexpr (std::is_same<T, float>::value) {
+                    if (rec32)
+                        hipLaunchKernelGGL((k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(F), dim3(WOL_SORT_BLOCK),
+                                           wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK, WOL_SORT_BLOCK, rec_size), ss, fv,
+                                           S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(), nrow_max);
+                }
+                if (!rec32)
                 hipLaunchKernelGGL((k_sort_rows<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
             } else {
@@ -727,7 +763,18 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                                    S.grids.as<FrameGrid>(), cntb, ro_stride, P);
                 hipLaunchKernelGGL(k_sort_rows_scan, dim3(F), dim3(WOL_SORT_BLOCK), 0, ss, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
                                    c->layer_off.as<int>(), ro_stride);
-                if (big_rows)
+                if constexpr (std::is_same<T, float>::value) {
+                    if (rec32 && big_rows)
+                        hipLaunchKernelGGL((k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK),
+                                           wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_BIG, WOL_SORT_BLOCK, rec_size), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                                           c->sort_tmp.as<float4>(), nrow_max);
+                    else if (rec32)
+                        hipLaunchKernelGGL((k_sort_rows_scatter<float, WOL_L1_CHUNK, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK),
+                                           wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK, WOL_SORT_BLOCK, rec_size), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                                           c->sort_tmp.as<float4>(), nrow_max);
+                }
+                if (rec32) {
+                } else if (big_rows)
                     hipLaunchKernelGGL((k_sort_rows_scatter<T, WOL_L1_CHUNK_BIG>), dim3(P, F), dim3(WOL_SORT_BLOCK),
                                        wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_BIG), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
                                        c->sort_tmp.as<double4>(), nrow_max);
@@ -784,7 +831,7 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         c->last_set = &S;
         bp->S = &S;
         bp->use_fast = use_fast; bp->rows_kernel = rows_kernel; bp->level_early = level_early; bp->pipe = pipe;
-        bp->tiles_max = tiles_max; bp->s32 = s32; bp->cnt4 = cnt4; bp->ss = ss; bp->qs = qs;
+        bp->tiles_max = tiles_max; bp->s32 = s32; bp->cnt4 = cnt4; bp->ss = ss; bp->qs = qs; bp->rec32 = rec32;
     }
     bp->gh = gh;
     bp->n_cell_frames = n_cell_frames;
@@ -796,7 +843,8 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
 // out.* are device pointers laid out [F][ns]...; sub (device, nullable) only with F == 1.
 template <typename T>
 int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_host, const T* sub,
-                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0, bool need_set = false) {
+                int64_t sub_stride, int ns, double low, double high, QOut out, int allow_pipe = 0, bool need_set = false,
+                bool want_rec32 = false) {
     const int n = fv.n;
     c->stat_slots = 0;   // (set again below when the certification kernel keeps per-wave partial sums)
     if (F <= 0 || ns <= 0) return WOL_OK;
@@ -805,7 +853,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
     const bool force_brute = (c->path == 1) || (c->path == 0 && n <= 1024) || (sub != nullptr && !std::is_same<T, double>::value);
     const bool want_fast = (c->path == 0 || c->path == 3) && sub == nullptr && low == 0.0 && ns == n;
     BatchPlan bp;
-    WOL_TRY(sort_batch<T>(c, fv, F, boxes_host, c->cell_width, high, want_fast, force_brute, allow_pipe, &bp, need_set));
+    WOL_TRY(sort_batch<T>(c, fv, F, boxes_host, c->cell_width, high, want_fast, force_brute, allow_pipe, &bp, need_set, want_rec32));
     const std::vector<int>& brute_frames = bp.brute_frames;
     if (bp.n_cell_frames > 0) {
         wol_ctx::SortSet& S = *bp.S;
@@ -875,6 +923,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = 0;
             c->last_rows_block = rows_kernel ? rows_block : 0;
+            c->last_rec_bytes = bp.rec32 ? 16 : 32;
             if (!rows_kernel) WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
             else if (rows_block == WOL_ROWS_BLOCK_B) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>, WOL_ROWS_BLOCK_B, 0, ftotal, &fgrid, c->search_margin));
             else WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>, WOL_ROWS_BLOCK_A, 0, ftotal, &fgrid, c->search_margin));
@@ -896,7 +945,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             const int64_t wtotal = (int64_t)F * n;
             int ggrid = 0;
             const bool lean = fa.fast_q && !out.nn_idx && !out.nn_dist;
-            if (lean) WOL_TRY(resident_grid(c, k_finish_fast<true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            const bool rec32 = bp.rec32;   // (float4 records: only behind the row kernel, see sort_batch)
+            if (rec32 && lean) WOL_TRY(resident_grid(c, k_finish_fast<true, float4>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            else if (rec32) WOL_TRY(resident_grid(c, k_finish_fast<false, float4>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            else if (lean) WOL_TRY(resident_grid(c, k_finish_fast<true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             else WOL_TRY(resident_grid(c, k_finish_fast<false>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             if (fa.xcd_affine) ggrid = std::max(8, (ggrid / 8) * 8);
             fa.stat_part = nullptr; fa.stat_slots = 0;
@@ -911,12 +963,20 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                     c->stat_slots = slots;
                 }
             }
-            if (lean) hipLaunchKernelGGL(k_finish_fast<true>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            if (rec32 && lean) hipLaunchKernelGGL((k_finish_fast<true, float4>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            else if (rec32) hipLaunchKernelGGL((k_finish_fast<false, float4>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            else if (lean) hipLaunchKernelGGL(k_finish_fast<true>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             else hipLaunchKernelGGL(k_finish_fast<false>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             int lgrid = 0;
-            WOL_TRY(resident_grid(c, k_search_exact_list, WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
-            hipLaunchKernelGGL(k_search_exact_list, dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
-                               c->slow_list.as<unsigned long long>(), fa.slow_count);
+            if (rec32) {
+                WOL_TRY(resident_grid(c, k_search_exact_list<float4>, WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
+                hipLaunchKernelGGL(k_search_exact_list<float4>, dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
+                                   c->slow_list.as<unsigned long long>(), fa.slow_count);
+            } else {
+                WOL_TRY(resident_grid(c, k_search_exact_list<double4>, WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
+                hipLaunchKernelGGL(k_search_exact_list<double4>, dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
+                                   c->slow_list.as<unsigned long long>(), fa.slow_count);
+            }
         } else {
             if (c->time_kernels) WOL_TRY(begin_timing(c, &ev));
             hipLaunchKernelGGL(k_search_exact, dim3(grid), dim3(WOL_BLOCK), hist_lds, c->stream, a);
@@ -1431,7 +1491,8 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         }
         const int pipe_mode = host ? 0 : (b == 0 ? 1 : 2);
         // (a packed batch narrowed to float32 runs the float instantiation: exact promotion, identical results)
-        if (bv.f32) WOL_TRY(run_q_batch<float>(c, view_as<float>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0));
+        if (bv.f32) WOL_TRY(run_q_batch<float>(c, view_as<float>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0,
+                                               npops == 0));   // (the population kernels read double4 records)
         else WOL_TRY(run_q_batch<double>(c, view_as<double>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0));
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
@@ -1925,6 +1986,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->skip_empty = value != 0.0;
     } else if (k == "pair_tiled") {
         c->pair_tiled = value != 0.0;
+    } else if (k == "rec32") {
+        c->rec32 = value != 0.0 ? 1 : 0;
     } else if (k == "host_pack") {
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail(WOL_ERR_INVALID, "host_pack must be 0, 1 or 2");
         c->host_pack = (int)value;
@@ -2005,6 +2068,10 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
     }
     if (std::string(key) == "rows_block") {  // k_search_rows instantiation of the last batch (threads per block)
         *value = c->last_rows_block;
+        return WOL_OK;
+    }
+    if (std::string(key) == "record_bytes") {  // storage form of the last q batch's sorted records (wol_rec): 32, or 16 for float32 frames
+        *value = c->last_rec_bytes;
         return WOL_OK;
     }
     if (std::string(key) == "density_level") {  // tile-shape level of frame 0 of the last batch

@@ -49,6 +49,32 @@ struct FrameGrid {
     int eps_units;      // bound on |fp32 key - exact d^2 * S|
 };
 
+// A water in the cell-sorted arrays: (x, y, z, original index).  Two storage forms: double4 (index as the bits of .w) and,
+// for frames stored as float32, float4 -- single-precision values are carried as they are (16 bytes instead of 32 through
+// both sort levels and in the certification kernel's gathers) and promoted, exactly, where the fp64 arithmetic starts.
+template <class REC> struct wol_rec;
+template <> struct wol_rec<double4> {
+    static __device__ __forceinline__ double4 make(double x, double y, double z, int orig) {
+        double4 v;
+        v.x = x; v.y = y; v.z = z; v.w = __longlong_as_double((long long)orig);
+        return v;
+    }
+    static __device__ __forceinline__ double4 wide(const double4& r) { return r; }
+};
+template <> struct wol_rec<float4> {
+    static __device__ __forceinline__ float4 make(double x, double y, double z, int orig) {   // (x, y, z came from floats)
+        float4 v;
+        v.x = (float)x; v.y = (float)y; v.z = (float)z; v.w = __int_as_float(orig);
+        return v;
+    }
+    static __device__ __forceinline__ double4 wide(const float4& r) {
+        double4 v;
+        v.x = (double)r.x; v.y = (double)r.y; v.z = (double)r.z; v.w = __longlong_as_double((long long)__float_as_int(r.w));
+        return v;
+    }
+};
+template <class REC> __device__ __forceinline__ double4 wol_rec_load(const REC* __restrict__ p, int64_t i) { return wol_rec<REC>::wide(p[i]); }
+
 __device__ __forceinline__ double wol_minimg1(double d, double L, double ib) {
     // distvec - BoxL*anint(distvec*iBoxL)   (waterlib.f90:44); round() is half-away like anint
     return d - L * round(d * ib);

@@ -309,8 +309,8 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
 #define WOL_L1_CHUNK_BIG 2        // ... for frames with more rows than WOL_L1_MAXROWS (tables up to WOL_L1_MAXROWS_BIG rows)
 #define WOL_L1_MAXROWS_BIG 6800
 // dynamic LDS of the level-1 kernels for a frame with nrow cell rows and chunks of ch * 1024 waters
-__host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch, int block = WOL_SORT_BLOCK) {
-    return (size_t)ch * block * (sizeof(double4) + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
+__host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch, int block = WOL_SORT_BLOCK, size_t rec = sizeof(double4)) {
+    return (size_t)ch * block * (rec + sizeof(int)) + 3 * sizeof(int) * (size_t)(nrow + 1);
 }
 
 // The scatter of level 1 for waters [i_begin, i_end) of a frame, cnt[] holding the row cursors in tmp[]:
@@ -319,10 +319,10 @@ __host__ __device__ inline size_t wol_sort_rows_lds(int nrow, int ch, int block 
 // atomic = rank inside the row, a scan over the rows) and then written out in that order: a row's waters of the
 // chunk are consecutive lanes writing consecutive addresses.  The next chunk's coordinates are fetched while the
 // current one goes through LDS.  icnt[] must be zero on entry (and is on exit).
-template <typename T, int CH, int SB = WOL_SORT_BLOCK>
+template <typename T, int CH, int SB = WOL_SORT_BLOCK, class REC = double4>
 __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base, int64_t atom_stride, int i_begin, int i_end,
-                                                     const FrameGrid& g, int* cnt, int* icnt, int* delta, double4* stage,
-                                                     int* dest, int* wtot, double4* __restrict__ out) {
+                                                     const FrameGrid& g, int* cnt, int* icnt, int* delta, REC* stage,
+                                                     int* dest, int* wtot, REC* __restrict__ out) {
     constexpr int C = CH * SB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
@@ -386,10 +386,7 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
         for (int u = 0; u < CH; ++u)
             if (row[u] >= 0) {
                 const int k = icnt[row[u]] + lr[u];
-                double4 v;
-                v.x = x[u]; v.y = y[u]; v.z = z[u];
-                v.w = __longlong_as_double((long long)(c0 + u * SB + tid));
-                stage[k] = v;
+                stage[k] = wol_rec<REC>::make(x[u], y[u], z[u], c0 + u * SB + tid);
                 dest[k] = k + delta[row[u]];
             }
         __syncthreads();
@@ -431,13 +428,13 @@ __device__ __forceinline__ void wol_sort_rows_count(const T* __restrict__ base, 
 }
 
 // one block per frame: count, scan, scatter (the batch has enough frames to fill the chip)
-template <typename T, int SB, int CH>
+template <typename T, int SB, int CH, class REC = double4>
 __global__ void __launch_bounds__(SB)
 k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
-            double4* __restrict__ tmp, int nrow_cap) {
+            REC* __restrict__ tmp, int nrow_cap) {
     extern __shared__ double4 lds_sort_rows[];
     constexpr int C = CH * SB;
-    double4* stage = lds_sort_rows;                                 // [C] the chunk in row order
+    REC* stage = reinterpret_cast<REC*>(lds_sort_rows);             // [C] the chunk in row order
     int* dest = reinterpret_cast<int*>(stage + C);                   // [C] its slots in tmp[]
     int* cnt = dest + C;                                             // [nrow + 1] row cursors in tmp[]
     int* icnt = cnt + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
@@ -470,8 +467,8 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     for (int k = sb; k < se; ++k) { const int v = cnt[k]; cnt[k] = run; ro[k] = run; run += v; }
     if (tid == SB - 1) ro[nrow] = part[SB - 1];
     __syncthreads();
-    wol_sort_rows_chunks<T, CH, SB>(base, fv.atom_stride, 0, fv.n, g, cnt, icnt, delta, stage, dest, wtot,
-                                          tmp + (int64_t)f * fv.n);
+    wol_sort_rows_chunks<T, CH, SB, REC>(base, fv.atom_stride, 0, fv.n, g, cnt, icnt, delta, stage, dest, wtot,
+                                         tmp + (int64_t)f * fv.n);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -482,13 +479,13 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
 // wave then collects its row from the frame's chunks (~3 waters of the row in each).  The row totals, summed as the
 // chunks go by, give the rows' places in the final arrays (row_off), as before.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int SB, int CH>
+template <typename T, int SB, int CH, class REC = double4>
 __global__ void __launch_bounds__(SB)
 k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
-                double4* __restrict__ tmp, unsigned short* __restrict__ tab, int tab_rows, int nchunk_cap, int nrow_cap) {
+                REC* __restrict__ tmp, unsigned short* __restrict__ tab, int tab_rows, int nchunk_cap, int nrow_cap) {
     extern __shared__ double4 lds_sort_rows[];
     constexpr int C = CH * SB;
-    double4* stage = lds_sort_rows;                                  // [C] the chunk in row order
+    REC* stage = reinterpret_cast<REC*>(lds_sort_rows);              // [C] the chunk in row order
     int* tot = reinterpret_cast<int*>(stage + C);                    // [nrow + 1] waters of the row so far
     int* icnt = tot + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
     __shared__ int part[SB];
@@ -497,7 +494,7 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
     const FrameGrid& g = grids[f];
     const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
     const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
-    double4* __restrict__ out = tmp + (int64_t)f * fv.n;
+    REC* __restrict__ out = tmp + (int64_t)f * fv.n;
     unsigned short* __restrict__ tb = tab + (int64_t)f * tab_rows * nchunk_cap;
     const int per = (nrow + SB - 1) / SB;
     const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
@@ -560,12 +557,7 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            if (row[u] >= 0) {
-                double4 v;
-                v.x = x[u]; v.y = y[u]; v.z = z[u];
-                v.w = __longlong_as_double((long long)(c0 + u * SB + tid));
-                stage[icnt[row[u]] + lr[u]] = v;
-            }
+            if (row[u] >= 0) stage[icnt[row[u]] + lr[u]] = wol_rec<REC>::make(x[u], y[u], z[u], c0 + u * SB + tid);
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -643,13 +635,13 @@ k_sort_rows_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cntb, in
 }
 
 // (c) block (p, f): its share of the frame into the row buckets, from its cursors
-template <typename T, int CH>
+template <typename T, int CH, class REC = double4>
 __global__ void __launch_bounds__(WOL_SORT_BLOCK)
 k_sort_rows_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const int* __restrict__ cntb, int stride, int P,
-                    double4* __restrict__ tmp, int nrow_cap) {
+                    REC* __restrict__ tmp, int nrow_cap) {
     extern __shared__ double4 lds_sort_rows[];
     constexpr int C = CH * WOL_SORT_BLOCK;
-    double4* stage = lds_sort_rows;
+    REC* stage = reinterpret_cast<REC*>(lds_sort_rows);
     int* dest = reinterpret_cast<int*>(stage + C);
     int* cnt = dest + C;
     int* icnt = cnt + (nrow_cap + 1);
@@ -662,8 +654,8 @@ k_sort_rows_scatter(FramesView<T> fv, const FrameGrid* __restrict__ grids, const
     for (int c = tid; c < nrow; c += WOL_SORT_BLOCK) { cnt[c] = cur[c]; icnt[c] = 0; }
     __syncthreads();
     const int per = (fv.n + P - 1) / P;
-    wol_sort_rows_chunks<T, CH>(fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, min(p * per, fv.n), min((p + 1) * per, fv.n),
-                                g, cnt, icnt, delta, stage, dest, wtot, tmp + (int64_t)f * fv.n);
+    wol_sort_rows_chunks<T, CH, WOL_SORT_BLOCK, REC>(fv.base + (int64_t)f * fv.frame_stride, fv.atom_stride, min(p * per, fv.n),
+                                                     min((p + 1) * per, fv.n), g, cnt, icnt, delta, stage, dest, wtot, tmp + (int64_t)f * fv.n);
 }
 
 // SLOTS waters per lane of a row are sorted through registers and LDS (rows of up to 64 * SLOTS waters; longer
@@ -694,17 +686,17 @@ struct RowPieces {
     int ny_cap;   // rows of a cell layer the block's LDS copy of the table has room for (+ 1)
 };
 
-template <int SLOTS>
+template <int SLOTS, class REC = double4>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
-              const double4* __restrict__ tmp, int n, int* __restrict__ cell_start,
-              double4* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap, RowPieces rp) {
+              const REC* __restrict__ tmp, int n, int* __restrict__ cell_start,
+              REC* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap, RowPieces rp) {
     extern __shared__ int lds_row_bins[];   // per wave: cnt[nb_cap] (per fine bin: population, then first slot in the row) and
                                             // cur[nb_cap] (long rows: running cursors); nb_cap >= nx * WOL_XSUB of every frame
     __shared__ int cpre_all[(WOL_BLOCK / 64) * (WOL_SEG_MAXCHUNK + 1)];   // segment form: waters of the row in earlier chunks
     __shared__ int csrc_all[(WOL_BLOCK / 64) * WOL_SEG_MAXCHUNK];         // ... and where water i of the row lies, minus i
     constexpr int WOL_L2_CAP = 64 * SLOTS;
-    __shared__ double4 st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];   // the row in bin order, written out linearly:
+    __shared__ REC st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];       // the row in bin order, written out linearly:
     __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
     const int f = blockIdx.y, cz = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -713,10 +705,10 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     if (cz >= nz || g.maxshell < 0 || nx * WOL_XSUB > nb_cap) return;   // (frames of the all-pairs path have no grid)
     int* cnt = lds_row_bins + wave * 2 * nb_cap;
     int* cur = cnt + nb_cap;
-    double4* st64 = st64_all + wave * WOL_L2_CAP;
+    REC* st64 = st64_all + wave * WOL_L2_CAP;
     float4* st32 = st32_all + wave * WOL_L2_CAP;
     const int* ro = row_off + (int64_t)f * ro_stride;
-    const double4* __restrict__ in = tmp + (int64_t)f * n;
+    const REC* __restrict__ in = tmp + (int64_t)f * n;
     int* cpre = cpre_all + wave * (WOL_SEG_MAXCHUNK + 1);
     int* csrc = csrc_all + wave * WOL_SEG_MAXCHUNK;
     const unsigned short* __restrict__ tb = rp.tab ? rp.tab + (int64_t)f * rp.tab_rows * rp.nchunk_cap : nullptr;
@@ -732,7 +724,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         }
         __syncthreads();
     }
-    double4* __restrict__ so = sorted + (int64_t)f * n;
+    REC* __restrict__ so = sorted + (int64_t)f * n;
     float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
     const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
     // the proposal kernel's own expression for the fine bin of a staged coordinate (wol_search_rows.hip)
@@ -776,13 +768,16 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         for (int c = lane; c < nb; c += 64) cnt[c] = 0;
         __builtin_amdgcn_wave_barrier();
         const bool fits = e - b <= WOL_L2_CAP && e > b;
+        REC r[SLOTS];
         double4 v[SLOTS];
         float4 w[SLOTS];
         int bins[SLOTS], rank[SLOTS];
         if (fits) {
             // ---- the usual row: read once (the waters stay in registers), rank = returning LDS atomic ----
 #pragma unroll
-            for (int u = 0; u < SLOTS; ++u) v[u] = in[src_of(min(lane + 64 * u, e - b - 1))];   // all in flight together (e > b here)
+            for (int u = 0; u < SLOTS; ++u) r[u] = in[src_of(min(lane + 64 * u, e - b - 1))];   // all in flight together (e > b here)
+#pragma unroll
+            for (int u = 0; u < SLOTS; ++u) v[u] = wol_rec<REC>::wide(r[u]);
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) {
                 const int i = b + lane + 64 * u;
@@ -803,7 +798,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         } else {
             // ---- long rows: count first ----
             for (int i = lane; i < e - b; i += 64) {
-                const double4 p = in[src_of(i)];
+                const double4 p = wol_rec_load(in, src_of(i));
                 double ux = p.x * g.box.ib[0]; ux -= floor(ux);
                 int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);
                 const float wx = (float)((ux * (double)nx - (double)cx) * sx);
@@ -853,7 +848,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             for (int u = 0; u < SLOTS; ++u)
                 if (bins[u] >= 0) {
                     const int d = cnt[bins[u]] + rank[u];
-                    st64[d] = v[u];
+                    st64[d] = r[u];
                     w[u].w = wol_pack_cell_tag(bins[u] / WOL_XSUB, bins[u] % WOL_XSUB, rank[u]);
                     st32[d] = w[u];
                 }
@@ -867,7 +862,8 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         }
         // ---- long rows: scatter straight into the final arrays ----
         for (int i = lane; i < e - b; i += 64) {
-            const double4 p = in[src_of(i)];
+            const REC praw = in[src_of(i)];
+            const double4 p = wol_rec<REC>::wide(praw);
             double ux = p.x * g.box.ib[0]; ux -= floor(ux);
             double uy = p.y * g.box.ib[1]; uy -= floor(uy);
             double uz = p.z * g.box.ib[2]; uz -= floor(uz);
@@ -879,7 +875,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             const int sub = min(WOL_XSUB - 1, (int)(q.x * inv_wf));
             const int bin = cx * WOL_XSUB + sub;
             const int dst = atomicAdd(&cur[bin], 1);
-            so[b + dst] = p;
+            so[b + dst] = praw;
             if (so32) {
                 q.w = wol_pack_cell_tag(cx, sub, dst - cnt[bin]);
                 so32[b + dst] = q;

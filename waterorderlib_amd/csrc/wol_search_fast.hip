@@ -718,7 +718,7 @@ __device__ __forceinline__ bool wol_lean_water(const FastArgs& a, const FrameGri
 #ifndef WOL_FINISH_WPS
 #define WOL_FINISH_WPS 4
 #endif
-template <bool LEAN>
+template <bool LEAN, class REC = double4>
 __global__ void __launch_bounds__(WOL_BLOCK, WOL_FINISH_WPS)
 k_finish_fast(FastArgs a) {
     extern __shared__ int lds_hist[];
@@ -743,7 +743,7 @@ k_finish_fast(FastArgs a) {
     long long sum_h = 0, sum_l = 0, sum_h2 = 0, sum_l2 = 0;  // this lane's share of frame f's sums of q, q^2
     const FrameGrid& g = a.grids[f];
     if (g.maxshell < 0) continue;  // all-pairs frame
-    const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+    const REC* __restrict__ sp = reinterpret_cast<const REC*>(a.sorted) + (int64_t)f * a.n;
     const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
     for (int s0 = kb * WOL_BLOCK; s0 < a.n; s0 += KB * WOL_BLOCK) {  // uniform bounds: whole waves stay in the loop
         const int s = min(s0 + (int)threadIdx.x, a.n - 1);
@@ -753,7 +753,7 @@ k_finish_fast(FastArgs a) {
         // (fetching the next 256 waters' share ahead of time was measured: no change, the gathers are what costs)
         const int kd3 = live ? a.prop_key[w] : 0;
         const int4 pr_all = a.prop[w];
-        const double4 mev_all = sp[s];
+        const double4 mev_all = wol_rec_load(sp, s);
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
         if constexpr (LEAN) { if (live && !slow) {
@@ -764,10 +764,10 @@ k_finish_fast(FastArgs a) {
             const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
 #ifdef WOL_EXP_FINISH_COALESCED   // ablation build: timing only, results are wrong (neighbours = the next four slots)
-            const double4 nb[4] = {sp[min(s + 1 + (pr.x & 0), a.n - 1)], sp[min(s + 2 + (pr.y & 0), a.n - 1)],
-                                   sp[min(s + 3 + (pr.z & 0), a.n - 1)], sp[min(s + 4 + (pr.w & 0), a.n - 1)]};
+            const double4 nb[4] = {wol_rec_load(sp, min(s + 1 + (pr.x & 0), a.n - 1)), wol_rec_load(sp, min(s + 2 + (pr.y & 0), a.n - 1)),
+                                   wol_rec_load(sp, min(s + 3 + (pr.z & 0), a.n - 1)), wol_rec_load(sp, min(s + 4 + (pr.w & 0), a.n - 1))};
 #else
-            const double4 nb[4] = {sp[pr.x], sp[pr.y], sp[pr.z], sp[pr.w]};
+            const double4 nb[4] = {wol_rec_load(sp, pr.x), wol_rec_load(sp, pr.y), wol_rec_load(sp, pr.z), wol_rec_load(sp, pr.w)};
 #endif
             const double nbx[4] = {nb[0].x, nb[1].x, nb[2].x, nb[3].x}, nby[4] = {nb[0].y, nb[1].y, nb[2].y, nb[3].y},
                          nbz[4] = {nb[0].z, nb[1].z, nb[2].z, nb[3].z};
@@ -777,7 +777,7 @@ k_finish_fast(FastArgs a) {
             const int4 pr = pr_all;
             const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
-            const double4 n0 = sp[pr.x], n1 = sp[pr.y], n2 = sp[pr.z], n3 = sp[pr.w];
+            const double4 n0 = wol_rec_load(sp, pr.x), n1 = wol_rec_load(sp, pr.y), n2 = wol_rec_load(sp, pr.z), n3 = wol_rec_load(sp, pr.w);
             Top4 t;
             top4_init(t);
             double dist;
@@ -895,6 +895,7 @@ __device__ __forceinline__ void wol_top4_wave_merge(Top4& t) {
     }
 }
 
+template <class REC>   // storage form of the sorted records (wol_rec: double4, or float4 for float32 frames)
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_list,
                     const int* __restrict__ slow_count) {
@@ -912,9 +913,9 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
         const unsigned long long e = slow_list[i];
         const int f = (int)(e >> 32), s = (int)(e & 0xFFFFFFFFu);
         const FrameGrid& g = a.grids[f];
-        const double4* __restrict__ sp = a.sorted + (int64_t)f * a.n;
+        const REC* __restrict__ sp = reinterpret_cast<const REC*>(a.sorted) + (int64_t)f * a.n;
         const int* __restrict__ cs = a.cell_start + g.cell_base;
-        const double4 v = sp[s];
+        const double4 v = wol_rec_load(sp, s);
         const double c[3] = {v.x, v.y, v.z};
         double fr[3];
         int cc[3];
@@ -946,7 +947,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
                 const int cell = (cz * g.nc[1] + cy) * g.nc[0] + cx;
                 const int b = cs[cell], en = cs[cell + 1];
                 for (int j = b; j < en; ++j) {
-                    const double4 p = sp[j];
+                    const double4 p = wol_rec_load(sp, j);
                     double dist;
                     bool in_mask;
                     if (wol_eval_pair(c, p.x, p.y, p.z, g.box, a.lowsq, a.highsq, mine.bound2, &dist, &in_mask))
@@ -966,7 +967,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
             if (all.n == 4 && all.d3 <= rg) break;
         }
         if (lane == 0) {
-            const double4 n0 = sp[all.s0], n1 = sp[all.s1], n2 = sp[all.s2], n3 = sp[all.s3];
+            const double4 n0 = wol_rec_load(sp, all.s0), n1 = wol_rec_load(sp, all.s1), n2 = wol_rec_load(sp, all.s2), n3 = wol_rec_load(sp, all.s3);
             const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
             const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
             wol_finish_water(c, all, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + (int)__double_as_longlong(v.w),
