@@ -336,6 +336,10 @@ def main():
     slow_last = ctx.counter("slow_waters")
     dens_level = ctx.counter("density_level")
     rows_block = ctx.counter("rows_block")
+    try:
+        grid_cells = [ctx.counter("cells_x"), ctx.counter("cells_y"), ctx.counter("cells_z")]
+    except Exception:   # (a library build from before the counter existed: tools/ab.sh)
+        grid_cells = None
 
     if rank == 0:
         kname = "k_search_rows" if args.search_rows != 0 else "k_search_fast"
@@ -400,6 +404,8 @@ def main():
                          "alg_bytes_per_water": bytes_per_water,
                          "exact_path_fraction_last_launch": slow_last / float(F * n),
                          "tile_density_level": dens_level, "proposal_block_threads": rows_block,
+                         "tile_cells": [ctx.counter("tile_sx"), ctx.counter("tile_ry")],
+                         "grid_cells": grid_cells,
                          "alg_bytes_per_launch": alg_bytes,
                          "secondary": secondary},
         }

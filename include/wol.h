@@ -93,6 +93,8 @@ int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int r
 /* diagnostic counters of the LAST q call on this context (synchronises the stream):
  * "slow_waters" = waters the fp32 filter could not certify and the exact search finished;
  * "density_level" = tile-shape level the device picked for frame 0 (0 = box-average density);
+ * "tile_sx" / "tile_ry" / "tiles_per_frame" = the proposal kernel's tiles of frame 0 at that level (cells along x, cell rows
+ * along y); "cells_x" / "cells_y" / "cells_z" = frame 0's grid;
  * "rows_block" = threads per block of the k_search_rows instantiation that ran (0: another proposal kernel);
  * "h2d_bytes" = bytes the last host-memory trajectory call sent over the host link;
  * "record_bytes" = size of a sorted record in the last q batch (32; 16 for float32 frames, option "rec32");

@@ -9,6 +9,6 @@ for round in 1 2; do
 import json,sys
 d=json.loads(sys.stdin.read())
 r=d['roofline']
-print('%-40s %8.0f frames/s  step %.3f ms  %s %.3f ms  slow %.2e' % ('$lib', d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], r['exact_path_fraction_last_launch']))"
+print('%-40s %8.0f frames/s  step %.3f ms  %s %.3f ms  slow %.2e  level %s tile %s' % ('$lib', d['value'], d['ms_per_step'], r['kernel'], r['avg_launch_ms'], r['exact_path_fraction_last_launch'], r['tile_density_level'], r.get('tile_cells')))"
   done
 done

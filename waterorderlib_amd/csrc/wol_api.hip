@@ -196,10 +196,8 @@ void build_tile_tables(const int nc[3], int n, int rows_block, TileTables* t) {
     // waters as fit one sweep of the block (one lane per water) while the halo'd tile ((sz+2) layers
     // of (ry+2) x (sx+2) cells, each padded to an even count, +15 %) fits the LDS pair buffer and the
     // row tables; among the fullest shapes the one with the smallest halo.
-    // densest tile-sized window / box average.  (Twelve levels in steps of 19 % were tried in round 3: tiles sized closer to
-    // the local density, but the shapes the search then picks for slabs -- 5 x 27 cells instead of 8 x 18 -- have half
-    // again as many triples per tile: 1.57 against 1.25 ms on the config-5 slab.  The lane-fill score does not see that.)
-    static const double lev_mult[WOL_NLEV] = {1.10, 1.35, 1.75, 2.4, 4.0, 8.0};
+    // densest tile-sized window / box average: levels in steps of ~11 % up to twice the mean, coarser beyond
+    static const double lev_mult[WOL_NLEV] = {1.10, 1.22, 1.35, 1.50, 1.68, 1.90, 2.2, 2.6, 3.2, 4.0, 5.5, 8.0};
     t->nlev = WOL_NLEV;
     t->ntiles = 0;
     t->max_sx = t->max_ry = t->max_sz = 1;
@@ -243,32 +241,49 @@ void build_tile_tables(const int nc[3], int n, int rows_block, TileTables* t) {
     //      staged = (ry + 2) triples of three z rows, sx + 2 cells long ----
     // the tile search for one instantiation (block threads, capp staged pairs); returns the lane fill at level 0
     struct RowTiles { short sx[WOL_NLEV], ry[WOL_NLEV], ntx[WOL_NLEV], nty[WOL_NLEV]; double fill0; };
+    // What a tile costs the proposal kernel, fitted to the kernel's time over forced shapes on the 100 000-water box and the
+    // config-5 slab (tools/tile_sweep.sh, profiles/r03_tile_sweep.txt; 3.5 % rms over 26 shapes), in units of ~1 ns of a
+    // block slot: a fixed part per tile (barriers, tile set-up, the per-wave prologue and epilogue of the sweep), a part per
+    // triple (its bin tables), per 64 own waters (one wave's sweep) and per staged water (placement).  The fixed part is a
+    // quarter of a 32 x 5 tile -- which is why large tiles win even when their last sweep round is nearly empty, and why
+    // the lane-fill score used before picked 8 x 18-cell tiles on slabs where 27 x 6 takes 23 % less time.
+    auto tile_cost = [](int sxe, int re, double w) -> double {
+        const double own = (double)sxe * re * w, staged = (double)(re + 2) * (sxe + 2) * w;
+        return 6.43 + 0.49 * (re + 2) + 0.01494 * 64.0 * std::ceil(own / 64.0) + 0.01195 * staged;
+    };
     auto row_tiles = [&](int block, int capp, RowTiles* rt) {
         const int target = WOL_ROWS_TARGET(block);
         for (int l = 0; l < WOL_NLEV; ++l) {
             const double w = wpc * lev_mult[l] / 1.10;
             double best = -1.0, bq = 0.0;
             int bsx = 1, bry = 1, bntx = nc[0], bnty = nc[1];
-            for (int sx0 = 1; sx0 <= std::min(nc[0], WOL_ROWS_MAXSX); ++sx0) {
-                const int ntx = (nc[0] + sx0 - 1) / sx0, sx = (nc[0] + ntx - 1) / ntx;  // equalised
-                if (sx != sx0) continue;
-                for (int ry0 = 1; ry0 <= std::min(nc[1], WOL_ROWS_MAXRY); ++ry0) {
-                    const int nty = (nc[1] + ry0 - 1) / ry0, ry = (nc[1] + nty - 1) / nty;
-                    if (ry != ry0) continue;
+            for (int sx = 1; sx <= std::min(nc[0], WOL_ROWS_MAXSX); ++sx) {
+                const int ntx = (nc[0] + sx - 1) / sx, sx_last = nc[0] - (ntx - 1) * sx;
+                for (int ry = 1; ry <= std::min(nc[1], WOL_ROWS_MAXRY); ++ry) {
+                    const int nty = (nc[1] + ry - 1) / ry, ry_last = nc[1] - (nty - 1) * ry;
                     const double q = sx * ry * w;
                     const bool unit = (sx == 1 && ry == 1);
-                    if (q > (double)target && !unit) continue;
+                    // own waters: up to an eighth beyond the block's lanes (the sweep then takes a second, short round)
+                    if (q > 1.12 * (double)target && !unit) continue;
                     const double staged = 3.0 * (ry + 2) * (sx + 2) * w;
                     if (staged * 1.12 + (ry + 2) > 2.0 * capp && !unit) continue;
                     if ((ry + 2) * (((sx + 2) * WOL_XSUB + 2) / 2) > WOL_ROWS_BINW) continue;
-                    // fill of the block's lanes first (5 % bands), then the staging ratio
-                    const double band = std::floor(q / (0.05 * target));
-                    const double score = band - staged / (q * 100.0);
+                    // a layer's tiles: (ntx - 1) x (nty - 1) whole ones and the shorter ones along its edges
+                    const double layer = (ntx - 1) * ((nty - 1) * tile_cost(sx, ry, w) + tile_cost(sx, ry_last, w)) +
+                                         (nty - 1) * tile_cost(sx_last, ry, w) + tile_cost(sx_last, ry_last, w);
+                    const double score = 1.0e6 / layer;
                     if (score > best) { best = score; bsx = sx; bry = ry; bntx = ntx; bnty = nty; bq = q; }
                 }
             }
+            if (const char* force = getenv("WOL_FORCE_ROW_TILE")) {   // tuning hook (tools/tile_sweep.sh): "sx,ry" for every level
+                int fsx = 0, fry = 0;
+                if (sscanf(force, "%d,%d", &fsx, &fry) == 2 && fsx >= 1 && fsx <= std::min(nc[0], WOL_ROWS_MAXSX) && fry >= 1 &&
+                    fry <= std::min(nc[1], WOL_ROWS_MAXRY) && (fry + 2) * (((fsx + 2) * WOL_XSUB + 2) / 2) <= WOL_ROWS_BINW) {
+                    bsx = fsx; bry = fry; bntx = (nc[0] + fsx - 1) / fsx; bnty = (nc[1] + fry - 1) / fry; bq = fsx * fry * w;
+                }
+            }
             rt->sx[l] = (short)bsx; rt->ry[l] = (short)bry; rt->ntx[l] = (short)bntx; rt->nty[l] = (short)bnty;
-            if (l == 0) rt->fill0 = bq / (double)block;
+            if (l == 0) rt->fill0 = std::fmin(bq / (double)block, 1.0);
         }
     };
     RowTiles rta, rtb;
@@ -2048,6 +2063,11 @@ int wol_ctx_get_counter(wol_ctx* c, const char* key, int64_t* value) {
     }
     if (std::string(key) == "h2d_bytes") {   // bytes the last host-memory trajectory call sent over the link
         *value = (int64_t)c->last_h2d_bytes;
+        return WOL_OK;
+    }
+    if (std::string(key) == "cells_x" || std::string(key) == "cells_y" || std::string(key) == "cells_z") {   // grid of frame 0 of the last batch
+        const FrameGrid* g = c->grids_host.as<FrameGrid>();
+        *value = g ? g->nc[key[6] - 'x'] : 0;
         return WOL_OK;
     }
     if (std::string(key) == "tile_sx" || std::string(key) == "tile_ry" || std::string(key) == "tiles_per_frame") {

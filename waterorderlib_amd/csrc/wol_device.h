@@ -9,7 +9,7 @@
 #include <stdint.h>
 
 #define WOL_PI 3.1415926535897931
-#define WOL_NLEV 6
+#define WOL_NLEV 12
 
 struct Box3 {
     double L[3];   // BoxL
