@@ -128,7 +128,9 @@ k_search_rows(FastArgs a) {
     __shared__ int qrow[WOL_ROWS_MAXRY + 2];                     // own rows -> first query number
     __shared__ int s_flag, s_next;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    // (the wave number through readfirstlane: the compiler then keeps everything indexed by it -- the rows a wave stages, their
+    //  table entries, the loops over them -- in scalar registers and scalar branches instead of 64 identical lanes under EXEC masks)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NW = WOL_ROWS_BLOCK / 64;
     const bool aff = a.xcd_affine != 0;
     const int fstep = aff ? 8 : 1;
@@ -356,6 +358,7 @@ k_search_rows(FastArgs a) {
         // ---- phase 2: every water to its place, ONE pass: entry = first entry of the triple's bin + the waters of the rows
         //      below in that bin + its rank inside the bin.  A wave takes whole rows; the fetch of the next 64 waters is in
         //      flight while the current 64 are placed. ----
+#ifndef WOL_EXP_NO_PLACE   // (ablation build with -DWOL_EXP_NO_PLACE: instruction counts only, results are wrong)
         if (!overflow) {
             const unsigned char* __restrict__ ob8 = reinterpret_cast<const unsigned char*>(obins);
             int r = wave, i0 = 0;
@@ -423,6 +426,7 @@ k_search_rows(FastArgs a) {
                 rec[p + WOL_ROWS_CAPP + WOL_ROWS_PADP] = far;
             }
         }
+#endif
         __syncthreads();
         WOL_STAMP(4);
         if (tid == 0) s_flag = 0;   // (for the next tile: see the note at the kernel's first clear)
