@@ -58,6 +58,19 @@
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
 #endif
 
+// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (shifts inside the rows of 16, then the row totals
+// broadcast to the rows behind) where a __shfl_up step is a ds_bpermute, i.e. one more instruction for the LDS unit the
+// sweeps of the other blocks are reading their candidates through
+__device__ __forceinline__ int wol_wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // one candidate pair against the lane's water: two keys = squared distance in key units << 12 | entry number.
 // Coordinates are staged in units of sqrt(2^-20 key range), so d^2 comes out in [0, 1] and saturates through the CLAMP
 // modifier of its last fma; one more packed fma (x (2^20 - 1) + 2^23) turns it into the float whose mantissa IS the
@@ -279,12 +292,7 @@ k_search_rows(FastArgs a) {
                 const unsigned w01 = w0 + w1, wt = w01 + w2;
                 const int c0 = (int)(wt & 0xFFu), c1 = (int)((wt >> 8) & 0xFFu), c2 = (int)((wt >> 16) & 0xFFu), c3 = (int)(wt >> 24);
                 const int s = (c0 + c1) + (c2 + c3);
-                int inc = s;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int v = __shfl_up(inc, off, 64);
-                    if (lane >= off) inc += v;
-                }
+                const int inc = wol_wave_scan_incl(s);
                 const int run = inc - s;
                 unsigned* __restrict__ bt = bins + t * nbw;
                 unsigned* __restrict__ ob = obins + t * nbw;
@@ -303,14 +311,9 @@ k_search_rows(FastArgs a) {
             for (int r0 = 0; r0 < nrows; r0 += 64) {
                 const int r = r0 + lane;
                 const int len = (r < nrows) ? (int)rcnt[3 * r] + (int)rcnt[3 * r + 1] + (int)rcnt[3 * r + 2] : 0;
-                int inc = len;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int v = __shfl_up(inc, off, 64);
-                    if (lane >= off) inc += v;
-                }
+                const int inc = wol_wave_scan_incl(len);
                 if (r < nrows) rpre[r] = run + inc - len;
-                run += __shfl(inc, 63, 64);
+                run += __builtin_amdgcn_readlane(inc, 63);
             }
             if (lane == 0) {
                 rpre[nrows] = run;
@@ -318,12 +321,7 @@ k_search_rows(FastArgs a) {
             }
         } else if (wave == 1) {    // own rows (centre z row of triples 1..re, the tile's own cells)
             const int c = (lane < re) ? (int)rcnt[3 * (3 * (lane + 1) + 1) + 1] : 0;
-            int inc = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += v;
-            }
+            const int inc = wol_wave_scan_incl(c);
             if (lane < re) qrow[lane + 1] = inc;
             if (lane == 0) qrow[0] = 0;
         } else if (wave == 2) {    // first entry of every triple (even): its size is known from the row table already
@@ -334,12 +332,7 @@ k_search_rows(FastArgs a) {
             // the sub-bin populations must add up to the cell populations (they saturate at 255 per bin)
             if (lane < ntrip && (int)(bins[lane * nbw + 2 * (sxe + 2)] & 0xFFFFu) != tot) s_flag = 1;
             const int len = (tot + 1) & ~1;
-            int inc = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += v;
-            }
+            const int inc = wol_wave_scan_incl(len);
             if (lane < ntrip) {
                 tbase[lane] = inc - len;
                 if ((tot & 1) && inc <= 2 * WOL_ROWS_CAPP) {   // complete the triple's last pair with a far-away dummy
