@@ -69,7 +69,7 @@ int wol_ctx_synchronize(wol_ctx* ctx);
  * default 0: measured +0-2 % once the proposal kernel draws its tiles dynamically), "stages" (pipe depth with "overlap":
  * 2 = sort | proposal + certification (default), 3 = the certification of the batch before on a third stream as well),
  * "search_margin" (blocks per CU the proposal kernel leaves free for such an overlapped sort), "seg_sort" (first sort level: 1 = single-pass segment form for frames of 24 576 waters
- * and more, default; 2 = whenever it applies; 0 = row-bucket form), "dyn_tiles" (1 = the
+ * and more -- split over several blocks per frame for big frames in small batches -- default; 2 = whenever it applies; 0 = row-bucket form), "dyn_tiles" (1 = the
  * proposal kernel's blocks draw their tiles from per-XCD counters, default: -8 % kernel time against the fixed order, 0), "inputs_resident" (1 = the caller guarantees that device input buffers are complete in
  * memory when a call is made, not merely enqueued earlier on the stream, so the sort of one call may overlap
  * the previous call's kernels; default 0), "time_kernels" (0/1: HIP-event timing of the dominant kernel,

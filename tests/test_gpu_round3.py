@@ -630,3 +630,30 @@ def test_float32_frames_keep_16_byte_records_bit_for_bit(shape):
         assert np.array_equal(a, b)
     q64 = np.asarray(r64.q.cpu() if hasattr(r64.q, "cpu") else r64.q)
     assert np.array_equal(out[1][4], q64.astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_split_single_pass_sort_of_big_frames_in_small_batches(dtype):
+    """big frames in small batches: every frame's first sort level is split over P blocks.  Single-pass form (seg_sort = 1,
+    default: block p writes the chunks p, p + P, ... as they lie in LDS, the blocks' row totals are summed by
+    k_sort_rows_scan) against the counting form (seg_sort = 0: count / scan / scatter): per-water q, statistics and both
+    histograms bit for bit, float64 frames and float32 frames (16-byte records); forced block counts too (P = 3: a block
+    takes many chunks; P larger than the number of chunks)."""
+    import torch
+    from waterorderlib_amd import engine, synth, _lib
+    xyz, boxes = synth.water_frames(150000, 4, seed=11)
+    rng = np.random.default_rng(5)
+    xyz = np.stack([xyz[t][rng.permutation(xyz.shape[1])] for t in range(xyz.shape[0])])
+    fr = torch.as_tensor(xyz.astype(np.float32) if dtype == "f32" else xyz, device="cuda")
+    out = []
+    for seg, parts in ((0, 0), (1, 0), (1, 3), (1, 64)):
+        ctx = _lib.Context()
+        ctx.set_option("seg_sort", seg)
+        ctx.set_option("sort_parts", parts)
+        r = engine.tet_order_traj(fr, boxes, want_q=True, ctx=ctx)
+        torch.cuda.synchronize()
+        out.append([np.asarray(x.cpu()) for x in (r.mean, r.var, r.qhist, r.dhist, r.q)])
+        ctx.close()
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)

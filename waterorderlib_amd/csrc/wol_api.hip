@@ -650,7 +650,8 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         const bool in_row_long = (int64_t)n > 100 * (int64_t)std::max(nrow_all, 1);   // long rows (big boxes): four waters per lane
         // dynamic LDS of the second level: the waves' bin counters and, in the segment form, the layer's copy of the row table
         auto in_row_lds = [&](int nchunk, int ny_cap) -> size_t {
-            return sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64) + (nchunk ? sizeof(unsigned short) * (size_t)nchunk * ny_cap + 8 : 0);
+            return sizeof(int) * 2 * (size_t)nb_cap * (WOL_BLOCK / 64) +
+                   (nchunk ? sizeof(int) * (size_t)(WOL_BLOCK / 64) * (2 * nchunk + 1) + sizeof(unsigned short) * (size_t)nchunk * ny_cap + 8 : 0);
         };
         // does it fit next to the kernel's static arrays?  (raises the kernel's dynamic-LDS limit when it has to: a long thin
         // box has hundreds of rows per layer and a hundred chunks)
@@ -732,11 +733,17 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 c->sort_rows_lds_set = 1;
             }
+            // (chunks of the split single-pass form below: smaller where the row tables are big)
+            const int ch_p = big_rows ? WOL_L1_CHUNK_BIG : WOL_L1_CHUNK;
+            const int nchunk_p = (n + ch_p * WOL_SORT_BLOCK - 1) / (ch_p * WOL_SORT_BLOCK);
             if (P == 1 && pipe) {
                 // beside the proposal kernel of the previous batch: eight waves and a third of the LDS per block, so that
                 // the two share a CU instead of taking turns
@@ -752,15 +759,15 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all_frames + 1};
                 if constexpr (std::is_same<T, float>::value) {
                     if (rec32)
-                        hipLaunchKernelGGL((k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(F), dim3(WOL_SORT_BLOCK),
+                        hipLaunchKernelGGL((k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(1, F), dim3(WOL_SORT_BLOCK),
                                            wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK, WOL_SORT_BLOCK, rec_size), ss, fv,
                                            S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
-                                           c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);
+                                           c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, 1, (int*)nullptr, 0);
                 }
                 if (!rec32)
-                hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
+                hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(1, F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
-                                   c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max);
+                                   c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, 1, (int*)nullptr, 0);
             } else if (P == 1) {
                 if constexpr (std::is_same<T, float>::value) {
                     if (rec32)
@@ -771,6 +778,46 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 if (!rec32)
                 hipLaunchKernelGGL((k_sort_rows<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(), nrow_max);
+            } else if (c->seg_sort && !pipe && nchunk_p <= WOL_SEG_MAXCHUNK && 10 * ch_p * WOL_SORT_BLOCK >= 13 * nrow_max &&
+                       in_row_fits(in_row_lds(nchunk_p, ny_all_frames + 1))) {
+                // (a chunk must hold more than a water or so of every row: the second level gathers a row from its pieces in all
+                //  the chunks -- on the config-5 slab, 2 048-water chunks over 4 428 rows, it took 462 us instead of 219)
+                // big frames in small batches, single pass: P blocks per frame write the frame's chunks as they lie in LDS (block p
+                // the chunks p, p + P, ...) with the table of the rows' starts; their row totals are added up and scanned by
+                // k_sort_rows_scan -- no counting pass over the frame, one contiguous write stream per block
+                const int ch = ch_p, chunk_waters = ch * WOL_SORT_BLOCK, nchunk = nchunk_p;
+                P = std::min(P, nchunk);
+                WOL_TRY(c->seg_tab.ensure(sizeof(unsigned short) * (size_t)F * (size_t)(nrow_max + 1) * nchunk));
+                WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * P * ro_stride));   // per-block row totals
+                int* cntb = c->rank.as<int>();
+                pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all_frames + 1};
+                const size_t lds1 = wol_sort_rows_lds(nrow_max, ch, WOL_SORT_BLOCK, rec_size);
+                bool done = false;
+                if constexpr (std::is_same<T, float>::value) {
+                    if (rec32) {
+                        if (big_rows)
+                            hipLaunchKernelGGL((k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK), lds1, ss, fv,
+                                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
+                                               c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, P, cntb, ro_stride);
+                        else
+                            hipLaunchKernelGGL((k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK), lds1, ss, fv,
+                                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
+                                               c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, P, cntb, ro_stride);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    if (big_rows)
+                        hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG>), dim3(P, F), dim3(WOL_SORT_BLOCK), lds1, ss, fv,
+                                           S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
+                                           c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, P, cntb, ro_stride);
+                    else
+                        hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(P, F), dim3(WOL_SORT_BLOCK), lds1, ss, fv,
+                                           S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
+                                           c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, P, cntb, ro_stride);
+                }
+                hipLaunchKernelGGL(k_sort_rows_scan, dim3(F), dim3(WOL_SORT_BLOCK), 0, ss, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                                   c->layer_off.as<int>(), ro_stride);
             } else {
                 WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * P * ro_stride));   // per-block row counts, then cursors
                 int* cntb = c->rank.as<int>();

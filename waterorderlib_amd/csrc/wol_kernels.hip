@@ -479,10 +479,13 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
 // wave then collects its row from the frame's chunks (~3 waters of the row in each).  The row totals, summed as the
 // chunks go by, give the rows' places in the final arrays (row_off), as before.
 // ---------------------------------------------------------------------------------------------
+// Big frames in small batches: P blocks per frame (grid (P, F)), block p taking chunks p, p + P, ...; the blocks' row totals
+// go to cntb[f][p][row] and k_sort_rows_scan turns them into the rows' places (with P == 1 the block does that itself).
 template <typename T, int SB, int CH, class REC = double4>
 __global__ void __launch_bounds__(SB)
 k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
-                REC* __restrict__ tmp, unsigned short* __restrict__ tab, int tab_rows, int nchunk_cap, int nrow_cap) {
+                REC* __restrict__ tmp, unsigned short* __restrict__ tab, int tab_rows, int nchunk_cap, int nrow_cap,
+                int P, int* __restrict__ cntb, int cnt_stride) {
     extern __shared__ double4 lds_sort_rows[];
     constexpr int C = CH * SB;
     REC* stage = reinterpret_cast<REC*>(lds_sort_rows);              // [C] the chunk in row order
@@ -490,7 +493,7 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
     int* icnt = tot + (nrow_cap + 1);                                // [nrow + 1] the chunk's waters per row, then starts
     __shared__ int part[SB];
     __shared__ int wtot[SB / 64];
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrameGrid& g = grids[f];
     const int ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
     const T* __restrict__ base = fv.base + (int64_t)f * fv.frame_stride;
@@ -503,23 +506,23 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
     double nx_[CH], ny_[CH], nz_[CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u) {   // (clamped, unconditional loads: see wol_sort_rows_count)
-        const int i = min(u * SB + tid, i_end - 1);
-        const T* p = base + (int64_t)i * fv.atom_stride;
-        nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
+        const int i = min(p * C + u * SB + tid, i_end - 1);
+        const T* q = base + (int64_t)i * fv.atom_stride;
+        nx_[u] = (double)q[0]; ny_[u] = (double)q[1]; nz_[u] = (double)q[2];
     }
     __syncthreads();
-    int chunk = 0;
-    for (int c0 = 0; c0 < i_end; c0 += C, ++chunk) {
+    for (int chunk = p; (int64_t)chunk * C < i_end; chunk += P) {
+        const int c0 = chunk * C;
         const int cn = min(C, i_end - c0);
         double x[CH], y[CH], z[CH];
         int row[CH], lr[CH];
 #pragma unroll
         for (int u = 0; u < CH; ++u) { x[u] = nx_[u]; y[u] = ny_[u]; z[u] = nz_[u]; }
 #pragma unroll
-        for (int u = 0; u < CH; ++u) {   // the next chunk's coordinates travel while this one goes through LDS
-            const int i = min(c0 + C + u * SB + tid, i_end - 1);
-            const T* p = base + (int64_t)i * fv.atom_stride;
-            nx_[u] = (double)p[0]; ny_[u] = (double)p[1]; nz_[u] = (double)p[2];
+        for (int u = 0; u < CH; ++u) {   // the block's next chunk's coordinates travel while this one goes through LDS
+            const int i = (int)min((int64_t)c0 + (int64_t)P * C + u * SB + tid, (int64_t)i_end - 1);
+            const T* q = base + (int64_t)i * fv.atom_stride;
+            nx_[u] = (double)q[0]; ny_[u] = (double)q[1]; nz_[u] = (double)q[2];
         }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -566,6 +569,11 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
         }
         for (int k = sb; k < se; ++k) icnt[k] = 0;
         __syncthreads();
+    }
+    if (P > 1) {   // this block's share of the row totals; k_sort_rows_scan adds the shares up and scans them
+        int* __restrict__ o = cntb + ((int64_t)f * P + p) * cnt_stride;
+        for (int k = sb; k < se; ++k) o[k] = tot[k];
+        return;
     }
     // exclusive scan of the row totals: the rows' places in the final arrays
     int s = 0;
@@ -676,7 +684,7 @@ __device__ __forceinline__ float wol_pack_cell_tag(int cx, int sub, int rank) {
     return __uint_as_float((unsigned)cx | ((unsigned)sub << 8) | ((unsigned)rank << 10));
 }
 
-#define WOL_SEG_MAXCHUNK 128  // chunks of a frame the segment form of the first level may write (a power of two)
+#define WOL_SEG_MAXCHUNK 256  // chunks of a frame the segment form of the first level may write (a power of two)
 
 // where the rows' waters lie when the first level wrote segments (k_sort_rows_seg): chunk c of the frame holds the
 // waters [tab[c][row], tab[c][row + 1]) of every row, chunks are `chunk_waters` apart; tab == null: rows are contiguous
@@ -693,8 +701,6 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
               REC* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap, RowPieces rp) {
     extern __shared__ int lds_row_bins[];   // per wave: cnt[nb_cap] (per fine bin: population, then first slot in the row) and
                                             // cur[nb_cap] (long rows: running cursors); nb_cap >= nx * WOL_XSUB of every frame
-    __shared__ int cpre_all[(WOL_BLOCK / 64) * (WOL_SEG_MAXCHUNK + 1)];   // segment form: waters of the row in earlier chunks
-    __shared__ int csrc_all[(WOL_BLOCK / 64) * WOL_SEG_MAXCHUNK];         // ... and where water i of the row lies, minus i
     constexpr int WOL_L2_CAP = 64 * SLOTS;
     __shared__ REC st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];       // the row in bin order, written out linearly:
     __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
@@ -709,13 +715,15 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     float4* st32 = st32_all + wave * WOL_L2_CAP;
     const int* ro = row_off + (int64_t)f * ro_stride;
     const REC* __restrict__ in = tmp + (int64_t)f * n;
-    int* cpre = cpre_all + wave * (WOL_SEG_MAXCHUNK + 1);
-    int* csrc = csrc_all + wave * WOL_SEG_MAXCHUNK;
     const unsigned short* __restrict__ tb = rp.tab ? rp.tab + (int64_t)f * rp.tab_rows * rp.nchunk_cap : nullptr;
     const int nchunk = rp.tab ? (n + rp.chunk_waters - 1) / rp.chunk_waters : 0;
+    // segment form, per wave (dynamic LDS behind the bin counters): waters of the row in earlier chunks, and where water i of
+    // the row lies, minus i
+    int* cpre = lds_row_bins + (WOL_BLOCK / 64) * 2 * nb_cap + wave * (2 * rp.nchunk_cap + 1);
+    int* csrc = cpre + rp.nchunk_cap + 1;
     // the block's rows are the ny rows of cell layer cz: their table entries (and the next row's) are ny + 1 consecutive
     // 16-bit values per chunk -- fetched once, chunk by chunk, into LDS behind the waves' bin counters
-    unsigned short* tabl = reinterpret_cast<unsigned short*>(lds_row_bins + (WOL_BLOCK / 64) * 2 * nb_cap);
+    unsigned short* tabl = reinterpret_cast<unsigned short*>(lds_row_bins + (WOL_BLOCK / 64) * (2 * nb_cap + (rp.tab ? 2 * rp.nchunk_cap + 1 : 0)));
     if (tb) {
         const int w = ny + 1;
         for (int idx = threadIdx.x; idx < nchunk * w; idx += WOL_BLOCK) {
