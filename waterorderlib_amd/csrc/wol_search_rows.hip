@@ -139,7 +139,7 @@ k_search_rows(FastArgs a) {
     __shared__ int rpre[WOL_ROWS_MAXROWS + 1];                   // staged waters before the row
     __shared__ int tbase[WOL_ROWS_MAXTRIP + 1];                  // first entry of the triple (even)
     __shared__ int qrow[WOL_ROWS_MAXRY + 2];                     // own rows -> first query number
-    __shared__ int s_flag, s_next;
+    __shared__ int s_flag, s_next[2];   // (s_next: the tile number drawn by thread 0, two slots used in turn)
     const int tid = threadIdx.x;
     // (the wave number through readfirstlane: the compiler then keeps everything indexed by it -- the rows a wave stages, their
     //  table entries, the loops over them -- in scalar registers and scalar branches instead of 64 identical lanes under EXEC masks)
@@ -188,10 +188,13 @@ k_search_rows(FastArgs a) {
     // during the sweep (every thread has read it before the barrier in front of the sweep, and the next tile's first
     // barrier orders the clear before that tile's table phase)
     if (tid == 0) s_flag = 0;
+    int slot = 0;   // which s_next slot the next hand-over uses: a slot is rewritten two hand-overs later, i.e. behind a barrier
+                    // every thread passes after reading it
     if (dyn) {
-        if (tid == 0) s_next = atomicAdd(ctr, 1);
+        if (tid == 0) s_next[0] = atomicAdd(ctr, 1);
         __syncthreads();
-        w_next = s_next;
+        w_next = s_next[0];
+        slot = 1;
     }
     for (;; tile += tstep) {
         if (dyn) {
@@ -236,9 +239,10 @@ k_search_rows(FastArgs a) {
         if (dyn && tid == 0) w_next = atomicAdd(ctr, 1);   // (in flight until the end of this tile)
         if (__builtin_amdgcn_readfirstlane(tile_flag) == 0) {   // nothing in this tile row: on to the next number
             if (dyn) {
-                if (tid == 0) s_next = w_next;
+                if (tid == 0) s_next[slot] = w_next;
                 __syncthreads();
-                w_next = s_next;
+                w_next = s_next[slot];
+                slot ^= 1;
             }
             continue;
         }
@@ -252,7 +256,9 @@ k_search_rows(FastArgs a) {
         const int64_t frame_off = (int64_t)f * a.n;
         const float xc = 0.5f * (float)(sxe + 2), yc = 0.5f * (float)(re + 2);
 
-        __syncthreads();           // the previous tile is done with the LDS tables
+        // the previous tile must be done with the LDS tables: with dynamic tile numbers the barrier of the hand-over at its end
+        // (or of the kernel's first draw) is that point already
+        if (!dyn) __syncthreads();
         WOL_STAMP(0);
         // ---- phase 1: tables.  Threads 0 .. nrows-1: the three pieces (left halo cell, the tile's cells, right halo cell)
         //      of one staged row each, from cell_start.  The other waves, one per triple: the sub-bin populations of the
@@ -513,9 +519,10 @@ k_search_rows(FastArgs a) {
         }
         WOL_STAMP(5);
         if (dyn) {
-            if (tid == 0) s_next = w_next;
+            if (tid == 0) s_next[slot] = w_next;
             __syncthreads();
-            w_next = s_next;
+            w_next = s_next[slot];
+            slot ^= 1;
         }
     }
 }
