@@ -509,6 +509,14 @@ k_search_rows(FastArgs a) {
                         return (int)(__float_as_uint(recg[(e >> 1) * 4 + 2 + (e & 1)]) & sm);
                     };
                     prop.x = slot_of(k0); prop.y = slot_of(k1); prop.z = slot_of(k2); prop.w = slot_of(k3);
+                    {   // in ascending order of the slots (the certification does not care about the order): the k-th gathers
+                        // of a wave's 64 neighbouring waters then fall into the same few row segments of the sorted array
+                        // (certification 664 -> 654 us per step; no more than that: it is the number of lines, not their spread)
+                        int t0 = min(prop.x, prop.y), t1 = max(prop.x, prop.y), t2 = min(prop.z, prop.w), t3 = max(prop.z, prop.w);
+                        prop.x = min(t0, t2); prop.w = max(t1, t3);
+                        const int u = max(t0, t2), v = min(t1, t3);
+                        prop.y = min(u, v); prop.z = max(u, v);
+                    }
                     kd3 = (int)d3;
                 }
             }
