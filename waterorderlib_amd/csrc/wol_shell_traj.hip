@@ -401,7 +401,9 @@ __device__ __forceinline__ int wol_traj_lsi_walk(const TrajShellArgs& a, const F
             if (k < cap - 1) row[k * stride] = d2;
             ++k;
         }
-        if (d2 > a.highsq && d2 <= high2sq) {
+        // (the raw squared distance is never below the minimum-image one: a candidate whose d2 already lies above the best
+        //  raw square so far -- by more than the tie band below -- cannot take its place, and most cannot)
+        if (d2 > a.highsq && d2 <= high2sq && (!hn || d2 <= next_raw2 * (1.0 + 4e-15))) {
             const double rx = p.x - c[0], ry = p.y - c[1], rz = p.z - c[2];
             const double raw2 = wol_sumsq(rx, ry, rz);
             const int idx = (int)__double_as_longlong(p.w);
