@@ -84,7 +84,10 @@ int wol_ctx_synchronize(wol_ctx* ctx);
  * threads, 0 = min(16, hardware threads)), "rec32" (1 = float32 frames of the trajectory q calls keep their values as
  * 16-byte (x, y, z, index) float records through both sort levels and in the certification kernel's gathers, promoted
  * exactly where the fp64 arithmetic starts -- bit-identical results, half the sort's bytes; default; 0 = 32-byte double
- * records as for float64 frames) */
+ * records as for float64 frames), "idx_sort" (1 = float64 frames of the trajectory q calls go through the sort as 16-byte
+ * index records and the certification reads the coordinates from the caller's frames by original index -- bit-identical
+ * results, 44 % fewer bytes through the sort, but the certification's gathers lose their locality: measured 8-15 % slower
+ * per step, default 0) */
 int wol_ctx_set_option(wol_ctx* ctx, const char* key, double value);
 /* accumulated HIP-event time (ms) and launch count of the dominant (neighbour search + q) kernel
  * since the last reset; needs option time_kernels=1.  Synchronises the stream. */
@@ -97,7 +100,8 @@ int wol_ctx_kernel_time(wol_ctx* ctx, double* ms_total, int64_t* launches, int r
  * along y); "cells_x" / "cells_y" / "cells_z" = frame 0's grid;
  * "rows_block" = threads per block of the k_search_rows instantiation that ran (0: another proposal kernel);
  * "h2d_bytes" = bytes the last host-memory trajectory call sent over the host link;
- * "record_bytes" = size of a sorted record in the last q batch (32; 16 for float32 frames, option "rec32");
+ * "record_bytes" = size of a sorted record in the last q batch (32; 16 for float32 frames, option "rec32"; 4 = index
+ * records, option "idx_sort");
  * "proposals_written" / "proposals_expected" / "proposals_bad": see option "check_proposals" (accumulated, not per call) */
 int wol_ctx_get_counter(wol_ctx* ctx, const char* key, int64_t* value);
 

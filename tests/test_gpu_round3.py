@@ -657,3 +657,49 @@ def test_split_single_pass_sort_of_big_frames_in_small_batches(dtype):
     for other in out[1:]:
         for a, b in zip(out[0], other):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("shape", ["bench_like", "few_big", "long_rows", "thin_box", "far_away", "host_packed", "host_o_only"])
+def test_index_records_equal_the_fp64_records_bit_for_bit(shape):
+    """float64 frames of bare O rows go through the sort as 16-byte index records (fp32 position inside the cell + original
+    index | cell | fine bin; option idx_sort, default) and the certification / the exact search read the coordinates from
+    the caller's frames by original index -- against the classic 32-byte records (idx_sort = 0): per-water q, statistics and
+    both integer histograms bit for bit, over both forms of the single-pass first level (one block per frame, split over
+    blocks), long rows, thousands of short rows, frames thousands of boxes from the origin (a tenth of the waters then take
+    the exact path), host frames packed by the feeder and host frames that already are O rows."""
+    import torch
+    from waterorderlib_amd import engine, synth, _lib
+    rng = np.random.default_rng(23)
+    len_wat = 1
+    if shape == "bench_like":
+        xyz, boxes = synth.water_frames(40000, 70, seed=2)
+    elif shape == "few_big":
+        xyz, boxes = synth.water_frames(130000, 4, seed=3)
+    elif shape == "long_rows":
+        bx = np.array([570.0, 21.0, 21.0])                             # 16 rows of 1 900 waters: counted, then scattered
+        xyz = rng.random((64, 30000, 3)) * bx; boxes = np.tile(bx[None], (64, 1))
+    elif shape == "thin_box":
+        bx = np.array([21.0, 50.0, 1700.0])                            # 4 444 rows: the first level takes the counting form,
+        xyz = rng.random((8, 60000, 3)) * bx; boxes = np.tile(bx[None], (8, 1))   # i.e. classic records either way
+    elif shape == "far_away":
+        xyz, boxes = synth.water_frames(30000, 66, seed=4)
+        xyz = xyz + 3000.0 * boxes[:, None, :] * rng.integers(-1, 2, size=(xyz.shape[0], 1, 3))
+    elif shape == "host_packed":
+        xyz, boxes = synth.water_frames(30000, 70, seed=5, len_wat=4)
+        len_wat = 4
+    else:
+        xyz, boxes = synth.water_frames(30000, 70, seed=6)
+    xyz = np.ascontiguousarray(np.stack([x.reshape(-1, len_wat, 3)[rng.permutation(x.shape[0] // len_wat)].reshape(-1, 3) for x in xyz]))
+    host = shape.startswith("host")
+    fr = xyz if host else torch.as_tensor(xyz, device="cuda")
+    out = {}
+    for mode in (1, 0):
+        ctx = _lib.Context()
+        ctx.set_option("idx_sort", mode)
+        r = engine.tet_order_traj(fr, boxes, len_wat=len_wat, want_q=True, ctx=ctx)
+        torch.cuda.synchronize()
+        assert ctx.counter("record_bytes") == (4 if mode and shape != "thin_box" else 32)
+        out[mode] = [np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (r.mean, r.var, r.qhist, r.dhist, r.q)]
+        ctx.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b)

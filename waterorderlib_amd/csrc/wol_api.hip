@@ -116,7 +116,8 @@ struct wol_ctx {
                            // memory latency, running them side by side gains nothing; kept as an opt-in
     bool inputs_resident = false;
     size_t sort_rows_lds_set = 0;
-    size_t in_row_static_lds[4] = {0, 0, 0, 0}, in_row_dyn_limit[4] = {0, 0, 0, 0};   // k_sort_in_row<2> / <4> (+ 2: float4 records): static LDS, dynamic LDS allowed so far
+    size_t in_row_static_lds[6] = {0, 0, 0, 0, 0, 0}, in_row_dyn_limit[6] = {0, 0, 0, 0, 0, 0};   // k_sort_in_row<2> / <4> (+ 2: float4 records, + 4: index records): static LDS, dynamic LDS allowed so far
+    int idx_sort = 0;        // float64 frames: index records through the sort, fp64 from the source frame (option "idx_sort"; measured slower: off)
     int rec32 = 1;           // float32 frames keep 16-byte records through the sort and the certification (option "rec32"; 0 = promote in the first level)
     int last_rows_block = 0;
     int last_rec_bytes = 0;
@@ -490,6 +491,7 @@ struct BatchPlan {
     std::vector<int> brute_frames;     // frames without a grid (non-periodic axis, tiny inputs, forced): all-pairs kernels
     bool use_fast = false, rows_kernel = false, level_early = false, pipe = false;
     bool rec32 = false;                // the sorted records are float4 (float32 frames through the streaming sort: wol_rec)
+    bool idx = false;                  // index records (wol_idx_key): S.sorted holds one int per water, coordinates come from the frames
     int rows_block = 0, tiles_max = 0, tile_any_stride = 0;
     float4* s32 = nullptr;
     unsigned* cnt4 = nullptr;
@@ -627,7 +629,12 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         // (16-byte records: half the sort's traffic, half the bytes of the certification kernel's gathers); every other consumer
         // of a sorted set reads double4 records
         const bool rec32 = want_rec32 && std::is_same<T, float>::value && layer_sort && use_fast && rows_kernel && !pipe && c->rec32;
-        const size_t rec_size = rec32 ? sizeof(float4) : sizeof(double4);
+        // float64 frames of bare O rows (3 doubles per water, up to 2^20 waters) in the single-pass form of the first level:
+        // index records (wol_idx_key) -- decided below, once the form of the first level is known
+        const bool idx_ok = want_rec32 && std::is_same<T, double>::value && n <= (1 << WOL_IDX_BITS) && layer_sort &&
+                            use_fast && rows_kernel && !pipe && c->idx_sort && c->seg_sort;
+        bool idx = idx_ok;   // (tentatively: cleared below when the first level takes a form other than the single-pass one)
+        const size_t rec_size = (rec32 || idx_ok) ? sizeof(float4) : sizeof(double4);
         // second level of every sort: the rows (cell-sorted or merely bucketed) are sorted by fine x bin, with the bin
         // populations per cell, into the final arrays.  The row-merged proposal kernel stages from rows in that order.
         const bool in_row_stage = layer_sort || (use_fast && rows_kernel);
@@ -656,10 +663,11 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         // does it fit next to the kernel's static arrays?  (raises the kernel's dynamic-LDS limit when it has to: a long thin
         // box has hundreds of rows per layer and a hundred chunks)
         auto in_row_fits = [&](size_t dyn) -> bool {
-            const void* fn = rec32 ? (in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4, float4>) : reinterpret_cast<const void*>(&k_sort_in_row<2, float4>))
+            const void* fn = idx ? (in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4, float4, true>) : reinterpret_cast<const void*>(&k_sort_in_row<2, float4, true>))
+                           : rec32 ? (in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4, float4>) : reinterpret_cast<const void*>(&k_sort_in_row<2, float4>))
                                    : (in_row_long ? reinterpret_cast<const void*>(&k_sort_in_row<4>) : reinterpret_cast<const void*>(&k_sort_in_row<2>));
-            size_t& stat = c->in_row_static_lds[(in_row_long ? 1 : 0) + (rec32 ? 2 : 0)];
-            size_t& limit = c->in_row_dyn_limit[(in_row_long ? 1 : 0) + (rec32 ? 2 : 0)];
+            size_t& stat = c->in_row_static_lds[(in_row_long ? 1 : 0) + (idx ? 4 : rec32 ? 2 : 0)];
+            size_t& limit = c->in_row_dyn_limit[(in_row_long ? 1 : 0) + (idx ? 4 : rec32 ? 2 : 0)];
             if (!stat) {
                 hipFuncAttributes fa_;
                 if (hipFuncGetAttributes(&fa_, fn) != hipSuccess) return false;
@@ -678,7 +686,15 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         };
         auto launch_in_row = [&](int ro_stride) {
             const size_t lds = in_row_lds(pieces.tab ? pieces.nchunk_cap : 0, pieces.ny_cap);
-            if (rec32 && in_row_long)
+            if (idx && in_row_long)
+                hipLaunchKernelGGL((k_sort_in_row<4, float4, true>), dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<int>(), s32, cnt4, nb_cap, pieces);
+            else if (idx)
+                hipLaunchKernelGGL((k_sort_in_row<2, float4, true>), dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
+                                   c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(), n, S.cells.as<int>(),
+                                   S.sorted.as<int>(), s32, cnt4, nb_cap, pieces);
+            else if (rec32 && in_row_long)
                 hipLaunchKernelGGL((k_sort_in_row<4, float4>), dim3(std::max(nz_all, 1), F), dim3(WOL_BLOCK), lds, ss, S.grids.as<FrameGrid>(),
                                    c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(), n, S.cells.as<int>(),
                                    S.sorted.as<float4>(), s32, cnt4, nb_cap, pieces);
@@ -733,6 +749,8 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<double, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG, float4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
@@ -745,6 +763,7 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
             const int ch_p = big_rows ? WOL_L1_CHUNK_BIG : WOL_L1_CHUNK;
             const int nchunk_p = (n + ch_p * WOL_SORT_BLOCK - 1) / (ch_p * WOL_SORT_BLOCK);
             if (P == 1 && pipe) {
+                idx = false;
                 // beside the proposal kernel of the previous batch: eight waves and a third of the LDS per block, so that
                 // the two share a CU instead of taking turns
                 hipLaunchKernelGGL((k_sort_rows<T, WOL_L1_BLOCK_PIPE, WOL_L1_CHUNK_PIPE>), dim3(F), dim3(WOL_L1_BLOCK_PIPE),
@@ -757,6 +776,13 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 const int chunk_waters = WOL_L1_CHUNK * WOL_SORT_BLOCK, nchunk = (n + chunk_waters - 1) / chunk_waters;
                 WOL_TRY(c->seg_tab.ensure(sizeof(unsigned short) * (size_t)F * (size_t)(nrow_max + 1) * nchunk));
                 pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all_frames + 1};
+                if constexpr (std::is_same<T, double>::value) {
+                    if (idx)
+                        hipLaunchKernelGGL((k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4, true>), dim3(1, F), dim3(WOL_SORT_BLOCK),
+                                           wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK, WOL_SORT_BLOCK, rec_size), ss, fv,
+                                           S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
+                                           c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, 1, (int*)nullptr, 0);
+                }
                 if constexpr (std::is_same<T, float>::value) {
                     if (rec32)
                         hipLaunchKernelGGL((k_sort_rows_seg<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(1, F), dim3(WOL_SORT_BLOCK),
@@ -764,11 +790,12 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                                            S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
                                            c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, 1, (int*)nullptr, 0);
                 }
-                if (!rec32)
+                if (!rec32 && !idx)
                 hipLaunchKernelGGL((k_sort_rows_seg<T, WOL_SORT_BLOCK, WOL_L1_CHUNK>), dim3(1, F), dim3(WOL_SORT_BLOCK), wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK), ss, fv,
                                    S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<double4>(),
                                    c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, 1, (int*)nullptr, 0);
             } else if (P == 1) {
+                idx = false;
                 if constexpr (std::is_same<T, float>::value) {
                     if (rec32)
                         hipLaunchKernelGGL((k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), dim3(F), dim3(WOL_SORT_BLOCK),
@@ -793,6 +820,19 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 pieces = RowPieces{c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, chunk_waters, ny_all_frames + 1};
                 const size_t lds1 = wol_sort_rows_lds(nrow_max, ch, WOL_SORT_BLOCK, rec_size);
                 bool done = false;
+                if constexpr (std::is_same<T, double>::value) {
+                    if (idx) {
+                        if (big_rows)
+                            hipLaunchKernelGGL((k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK_BIG, float4, true>), dim3(P, F), dim3(WOL_SORT_BLOCK), lds1, ss, fv,
+                                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
+                                               c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, P, cntb, ro_stride);
+                        else
+                            hipLaunchKernelGGL((k_sort_rows_seg<double, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4, true>), dim3(P, F), dim3(WOL_SORT_BLOCK), lds1, ss, fv,
+                                               S.grids.as<FrameGrid>(), c->layer_off.as<int>(), ro_stride, c->sort_tmp.as<float4>(),
+                                               c->seg_tab.as<unsigned short>(), nrow_max + 1, nchunk, nrow_max, P, cntb, ro_stride);
+                        done = true;
+                    }
+                }
                 if constexpr (std::is_same<T, float>::value) {
                     if (rec32) {
                         if (big_rows)
@@ -819,6 +859,7 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 hipLaunchKernelGGL(k_sort_rows_scan, dim3(F), dim3(WOL_SORT_BLOCK), 0, ss, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
                                    c->layer_off.as<int>(), ro_stride);
             } else {
+                idx = false;
                 WOL_TRY(c->rank.ensure(sizeof(int) * (size_t)F * P * ro_stride));   // per-block row counts, then cursors
                 int* cntb = c->rank.as<int>();
                 hipLaunchKernelGGL(k_sort_rows_count<T>, dim3(P, F), dim3(WOL_SORT_BLOCK), sizeof(int) * (size_t)(nrow_max + 1), ss, fv,
@@ -893,7 +934,7 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
         c->last_set = &S;
         bp->S = &S;
         bp->use_fast = use_fast; bp->rows_kernel = rows_kernel; bp->level_early = level_early; bp->pipe = pipe;
-        bp->tiles_max = tiles_max; bp->s32 = s32; bp->cnt4 = cnt4; bp->ss = ss; bp->qs = qs; bp->rec32 = rec32;
+        bp->tiles_max = tiles_max; bp->s32 = s32; bp->cnt4 = cnt4; bp->ss = ss; bp->qs = qs; bp->rec32 = rec32; bp->idx = idx;
     }
     bp->gh = gh;
     bp->n_cell_frames = n_cell_frames;
@@ -938,6 +979,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
         a.out = out;
         a.tiles_per_frame = (ns + WOL_BLOCK - 1) / WOL_BLOCK;
         a.xcd_affine = (F >= 8) ? 1 : 0;
+        a.sidx = nullptr; a.src = nullptr; a.src_fstride = 0; a.src_astride = 3;
         const int64_t total = (int64_t)F * a.tiles_per_frame;
         int grid = 0;
         WOL_TRY(resident_grid(c, k_search_exact, WOL_BLOCK, hist_lds, total, &grid));
@@ -978,6 +1020,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             fa.cnt4 = cnt4;
             fa.work = nullptr;
             if (rows_kernel && c->dyn_tiles != 0) fa.work = S.work.as<int>();
+            fa.sidx = bp.idx ? S.sorted.as<int>() : nullptr;
+            fa.src = reinterpret_cast<const double*>(fv.base);   // (read only with index records: T is double then)
+            fa.src_fstride = fv.frame_stride; fa.src_astride = fv.atom_stride;
+            a.sidx = fa.sidx; a.src = fa.src; a.src_fstride = fa.src_fstride; a.src_astride = fa.src_astride;
 #ifdef WOL_PHASE_STAMPS
             WOL_TRY(c->stamps.ensure(sizeof(unsigned long long) * 8));
             fa.stamps = c->stamps.as<unsigned long long>();
@@ -985,7 +1031,7 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             const int64_t ftotal = (int64_t)F * tiles_max;
             int fgrid = 0;
             c->last_rows_block = rows_kernel ? rows_block : 0;
-            c->last_rec_bytes = bp.rec32 ? 16 : 32;
+            c->last_rec_bytes = bp.idx ? 4 : bp.rec32 ? 16 : 32;
             if (!rows_kernel) WOL_TRY(resident_grid(c, k_search_fast, WOL_FAST_BLOCK, 0, ftotal, &fgrid, 0));
             else if (rows_block == WOL_ROWS_BLOCK_B) WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_B, WOL_ROWS_CAPP_B>, WOL_ROWS_BLOCK_B, 0, ftotal, &fgrid, c->search_margin));
             else WOL_TRY(resident_grid(c, k_search_rows<WOL_ROWS_BLOCK_A, WOL_ROWS_CAPP_A>, WOL_ROWS_BLOCK_A, 0, ftotal, &fgrid, c->search_margin));
@@ -1008,7 +1054,10 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             int ggrid = 0;
             const bool lean = fa.fast_q && !out.nn_idx && !out.nn_dist;
             const bool rec32 = bp.rec32;   // (float4 records: only behind the row kernel, see sort_batch)
-            if (rec32 && lean) WOL_TRY(resident_grid(c, k_finish_fast<true, float4>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            const bool idx = bp.idx;
+            if (idx && lean) WOL_TRY(resident_grid(c, k_finish_fast<true, double4, true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            else if (idx) WOL_TRY(resident_grid(c, k_finish_fast<false, double4, true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
+            else if (rec32 && lean) WOL_TRY(resident_grid(c, k_finish_fast<true, float4>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             else if (rec32) WOL_TRY(resident_grid(c, k_finish_fast<false, float4>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             else if (lean) WOL_TRY(resident_grid(c, k_finish_fast<true>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
             else WOL_TRY(resident_grid(c, k_finish_fast<false>, WOL_BLOCK, hist_lds, (wtotal + WOL_BLOCK - 1) / WOL_BLOCK, &ggrid));
@@ -1025,12 +1074,18 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
                     c->stat_slots = slots;
                 }
             }
-            if (rec32 && lean) hipLaunchKernelGGL((k_finish_fast<true, float4>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            if (idx && lean) hipLaunchKernelGGL((k_finish_fast<true, double4, true>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            else if (idx) hipLaunchKernelGGL((k_finish_fast<false, double4, true>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
+            else if (rec32 && lean) hipLaunchKernelGGL((k_finish_fast<true, float4>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             else if (rec32) hipLaunchKernelGGL((k_finish_fast<false, float4>), dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             else if (lean) hipLaunchKernelGGL(k_finish_fast<true>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             else hipLaunchKernelGGL(k_finish_fast<false>, dim3(ggrid), dim3(WOL_BLOCK), hist_lds, c->stream, fa);
             int lgrid = 0;
-            if (rec32) {
+            if (idx) {
+                WOL_TRY(resident_grid(c, (k_search_exact_list<double4, true>), WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
+                hipLaunchKernelGGL((k_search_exact_list<double4, true>), dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
+                                   c->slow_list.as<unsigned long long>(), fa.slow_count);
+            } else if (rec32) {
                 WOL_TRY(resident_grid(c, k_search_exact_list<float4>, WOL_BLOCK, hist_lds, 1 << 20, &lgrid));
                 hipLaunchKernelGGL(k_search_exact_list<float4>, dim3(lgrid), dim3(WOL_BLOCK), hist_lds, c->stream, a,
                                    c->slow_list.as<unsigned long long>(), fa.slow_count);
@@ -1555,7 +1610,8 @@ int q_traj_impl(wol_ctx* c, const T* frames, int64_t atom_stride, int64_t frame_
         // (a packed batch narrowed to float32 runs the float instantiation: exact promotion, identical results)
         if (bv.f32) WOL_TRY(run_q_batch<float>(c, view_as<float>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0,
                                                npops == 0));   // (the population kernels read double4 records)
-        else WOL_TRY(run_q_batch<double>(c, view_as<double>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0));
+        else WOL_TRY(run_q_batch<double>(c, view_as<double>(bv, n), F, boxes + 3 * (size_t)f0, nullptr, 0, n, low, high, out, pipe_mode, npops > 0,
+                                         npops == 0));
         if (need_stats) {
             double* dm = host ? d_stats + f0 : (mean ? mean + f0 : nullptr);
             double* dv = host ? d_stats + T_frames + f0 : (var ? var + f0 : nullptr);
@@ -2050,6 +2106,8 @@ int wol_ctx_set_option(wol_ctx* c, const char* key, double value) {
         c->pair_tiled = value != 0.0;
     } else if (k == "rec32") {
         c->rec32 = value != 0.0 ? 1 : 0;
+    } else if (k == "idx_sort") {
+        c->idx_sort = value != 0.0 ? 1 : 0;
     } else if (k == "host_pack") {
         if (value != 0.0 && value != 1.0 && value != 2.0) return fail(WOL_ERR_INVALID, "host_pack must be 0, 1 or 2");
         c->host_pack = (int)value;

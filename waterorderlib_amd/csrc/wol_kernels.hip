@@ -299,6 +299,19 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
 //           by cx with per-wave LDS counters straight into the final arrays; consecutive rows are
 //           consecutive in the output, so those writes stream too.
 // ---------------------------------------------------------------------------------------------
+#ifndef WOL_XSUB
+#define WOL_XSUB 4            // fine x bins per cell (see k_sort_in_row)
+#endif
+// Index records ("IDX" forms of the sort, float64 frames of bare O rows on their way to the row-merged q pipeline): the first
+// level already knows everything the proposal kernel wants of a water -- its position inside its cell as fp32, its cell along
+// x and fine bin -- so it writes THAT (12 bytes) plus a key word = original index | cell << 20 | fine bin << 27 instead of a
+// 32-byte fp64 record; the second level orders these 16-byte records and writes the fp32 array and one int per water (the
+// original index by sorted slot).  No fp64 copy of the frame is made: the certification and the exact search read the 24-byte
+// rows of the SOURCE frame by original index (an O-only frame of 100 000 waters is 2.4 MB: it stays in the L2 of the XCD
+// that works on it).  76 instead of 136 bytes per water through the sort.
+#define WOL_IDX_BITS 20
+__device__ __forceinline__ unsigned wol_idx_key(int orig, int cx, int sub) { return (unsigned)orig | ((unsigned)cx << WOL_IDX_BITS) | ((unsigned)sub << (WOL_IDX_BITS + 7)); }
+
 #define WOL_L1_MAXROWS 4080   // nz * ny rows counted in LDS by level 1 (three tables + the chunk staging within 160 KB)
 #define WOL_L2_MAXNX 128      // cells of a row handled by one wave of level 2
 #ifndef WOL_L1_CHUNK
@@ -481,7 +494,7 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
 // ---------------------------------------------------------------------------------------------
 // Big frames in small batches: P blocks per frame (grid (P, F)), block p taking chunks p, p + P, ...; the blocks' row totals
 // go to cntb[f][p][row] and k_sort_rows_scan turns them into the rows' places (with P == 1 the block does that itself).
-template <typename T, int SB, int CH, class REC = double4>
+template <typename T, int SB, int CH, class REC = double4, bool IDX = false>   // (IDX: REC = float4, see wol_idx_key)
 __global__ void __launch_bounds__(SB)
 k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restrict__ row_off, int ro_stride,
                 REC* __restrict__ tmp, unsigned short* __restrict__ tab, int tab_rows, int nchunk_cap, int nrow_cap,
@@ -560,7 +573,28 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            if (row[u] >= 0) stage[icnt[row[u]] + lr[u]] = wol_rec<REC>::make(x[u], y[u], z[u], c0 + u * SB + tid);
+            if (row[u] >= 0) {
+                if constexpr (IDX) {
+                    // the fp32 record of k_sort_in_row, statement for statement (cy, cz are the row's, as there)
+                    const int nxc = g.nc[0];
+                    const int cyr = row[u] % ny, czr = row[u] / ny;
+                    double ux = x[u] * g.box.ib[0]; ux -= floor(ux);
+                    double uy = y[u] * g.box.ib[1]; uy -= floor(uy);
+                    double uz = z[u] * g.box.ib[2]; uz -= floor(uz);
+                    int cx = (int)(ux * (double)nxc); cx = cx >= nxc ? nxc - 1 : (cx < 0 ? 0 : cx);
+                    const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
+                    float4 w;
+                    w.x = (float)((ux * (double)nxc - (double)cx) * sx);
+                    w.y = (float)((uy * (double)ny - (double)cyr) * sy);
+                    w.z = (float)((uz * (double)nz - (double)czr) * sz);
+                    const float inv_wf = (float)WOL_XSUB / (float)(g.cw[0] * (double)g.scale);
+                    const int sub = min(WOL_XSUB - 1, (int)(w.x * inv_wf));
+                    w.w = __uint_as_float(wol_idx_key(c0 + u * SB + tid, cx, sub));
+                    stage[icnt[row[u]] + lr[u]] = w;
+                } else {
+                    stage[icnt[row[u]] + lr[u]] = wol_rec<REC>::make(x[u], y[u], z[u], c0 + u * SB + tid);
+                }
+            }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
@@ -694,15 +728,20 @@ struct RowPieces {
     int ny_cap;   // rows of a cell layer the block's LDS copy of the table has room for (+ 1)
 };
 
-template <int SLOTS, class REC = double4>
+template <bool IDX, class REC> struct wol_sorted_out { typedef REC type; };
+template <class REC> struct wol_sorted_out<true, REC> { typedef int type; };   // index records: the original index by sorted slot
+
+template <int SLOTS, class REC = double4, bool IDX = false>
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_off, int ro_stride,
               const REC* __restrict__ tmp, int n, int* __restrict__ cell_start,
-              REC* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4, int nb_cap, RowPieces rp) {
+              typename wol_sorted_out<IDX, REC>::type* __restrict__ sorted, float4* __restrict__ sorted32, unsigned* __restrict__ cnt4,
+              int nb_cap, RowPieces rp) {
+    typedef typename wol_sorted_out<IDX, REC>::type OUT;
     extern __shared__ int lds_row_bins[];   // per wave: cnt[nb_cap] (per fine bin: population, then first slot in the row) and
                                             // cur[nb_cap] (long rows: running cursors); nb_cap >= nx * WOL_XSUB of every frame
     constexpr int WOL_L2_CAP = 64 * SLOTS;
-    __shared__ REC st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];       // the row in bin order, written out linearly:
+    __shared__ OUT st64_all[(WOL_BLOCK / 64) * WOL_L2_CAP];       // the row in bin order, written out linearly:
     __shared__ float4 st32_all[(WOL_BLOCK / 64) * WOL_L2_CAP];    // full-line stores instead of a 32-byte scatter
     const int f = blockIdx.y, cz = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -711,7 +750,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
     if (cz >= nz || g.maxshell < 0 || nx * WOL_XSUB > nb_cap) return;   // (frames of the all-pairs path have no grid)
     int* cnt = lds_row_bins + wave * 2 * nb_cap;
     int* cur = cnt + nb_cap;
-    REC* st64 = st64_all + wave * WOL_L2_CAP;
+    OUT* st64 = st64_all + wave * WOL_L2_CAP;
     float4* st32 = st32_all + wave * WOL_L2_CAP;
     const int* ro = row_off + (int64_t)f * ro_stride;
     const REC* __restrict__ in = tmp + (int64_t)f * n;
@@ -732,7 +771,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         }
         __syncthreads();
     }
-    REC* __restrict__ so = sorted + (int64_t)f * n;
+    OUT* __restrict__ so = sorted + (int64_t)f * n;
     float4* __restrict__ so32 = sorted32 ? sorted32 + (int64_t)f * n : nullptr;
     const double sx = g.cw[0] * (double)g.scale, sy = g.cw[1] * (double)g.scale, sz = g.cw[2] * (double)g.scale;
     // the proposal kernel's own expression for the fine bin of a staged coordinate (wol_search_rows.hip)
@@ -784,6 +823,19 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             // ---- the usual row: read once (the waters stay in registers), rank = returning LDS atomic ----
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) r[u] = in[src_of(min(lane + 64 * u, e - b - 1))];   // all in flight together (e > b here)
+            if constexpr (IDX) {
+#pragma unroll
+                for (int u = 0; u < SLOTS; ++u) {
+                    const int i = b + lane + 64 * u;
+                    bins[u] = -1;
+                    if (i < e) {
+                        const unsigned key = __float_as_uint(r[u].w);
+                        w[u].x = r[u].x; w[u].y = r[u].y; w[u].z = r[u].z;
+                        bins[u] = (int)((key >> WOL_IDX_BITS) & 0x7Fu) * WOL_XSUB + (int)(key >> (WOL_IDX_BITS + 7));
+                        rank[u] = atomicAdd(&cnt[bins[u]], 1);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int u = 0; u < SLOTS; ++u) v[u] = wol_rec<REC>::wide(r[u]);
 #pragma unroll
@@ -803,9 +855,15 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
                     rank[u] = atomicAdd(&cnt[bins[u]], 1);
                 }
             }
+            }
         } else {
             // ---- long rows: count first ----
             for (int i = lane; i < e - b; i += 64) {
+                if constexpr (IDX) {
+                    const unsigned key = __float_as_uint(in[src_of(i)].w);
+                    atomicAdd(&cnt[(int)((key >> WOL_IDX_BITS) & 0x7Fu) * WOL_XSUB + (int)(key >> (WOL_IDX_BITS + 7))], 1);
+                    continue;
+                }
                 const double4 p = wol_rec_load(in, src_of(i));
                 double ux = p.x * g.box.ib[0]; ux -= floor(ux);
                 int cx = (int)(ux * (double)nx); cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx);
@@ -856,7 +914,8 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             for (int u = 0; u < SLOTS; ++u)
                 if (bins[u] >= 0) {
                     const int d = cnt[bins[u]] + rank[u];
-                    st64[d] = r[u];
+                    if constexpr (IDX) st64[d] = (int)(__float_as_uint(r[u].w) & ((1u << WOL_IDX_BITS) - 1u));
+                    else st64[d] = r[u];
                     w[u].w = wol_pack_cell_tag(bins[u] / WOL_XSUB, bins[u] % WOL_XSUB, rank[u]);
                     st32[d] = w[u];
                 }
@@ -871,6 +930,19 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
         // ---- long rows: scatter straight into the final arrays ----
         for (int i = lane; i < e - b; i += 64) {
             const REC praw = in[src_of(i)];
+            if constexpr (IDX) {
+                const unsigned key = __float_as_uint(praw.w);
+                const int cx = (int)((key >> WOL_IDX_BITS) & 0x7Fu), sub = (int)(key >> (WOL_IDX_BITS + 7));
+                const int bin = cx * WOL_XSUB + sub;
+                const int dst = atomicAdd(&cur[bin], 1);
+                so[b + dst] = (int)(key & ((1u << WOL_IDX_BITS) - 1u));
+                if (so32) {
+                    float4 q = praw;
+                    q.w = wol_pack_cell_tag(cx, sub, dst - cnt[bin]);
+                    so32[b + dst] = q;
+                }
+                continue;
+            }
             const double4 p = wol_rec<REC>::wide(praw);
             double ux = p.x * g.box.ib[0]; ux -= floor(ux);
             double uy = p.y * g.box.ib[1]; uy -= floor(uy);
@@ -883,7 +955,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
             const int sub = min(WOL_XSUB - 1, (int)(q.x * inv_wf));
             const int bin = cx * WOL_XSUB + sub;
             const int dst = atomicAdd(&cur[bin], 1);
-            so[b + dst] = praw;
+            if constexpr (!IDX) so[b + dst] = praw;
             if (so32) {
                 q.w = wol_pack_cell_tag(cx, sub, dst - cnt[bin]);
                 so32[b + dst] = q;
@@ -1051,6 +1123,10 @@ struct SearchArgs {
     QOut out;
     int tiles_per_frame;
     int xcd_affine;
+    // index records (see FastArgs): sidx[F][n] or null, the caller's frames of bare O rows
+    const int* sidx;
+    const double* src;
+    int64_t src_fstride, src_astride;
 };
 
 // tile -> (frame, tile in frame).  With >= 8 frames in flight the 8 XCDs (blocks b and b+8 share

@@ -87,7 +87,39 @@ struct FastArgs {
     const unsigned* cnt4;   // per cell: populations of its four fine x bins as bytes (k_sort_in_row); k_search_rows only
     long long* stat_part;   // [F][stat_slots][4]: per-wave partial sums of q, q^2 of k_finish_fast (zeroed by the host), or null
     int stat_slots;
+    // index records (wol_idx_key): no fp64 copy of the frames exists; sidx[F][n] = original index by sorted slot, the
+    // proposals name ORIGINAL indices, and coordinates are read from the caller's frames (bare O rows: 3 doubles per water)
+    const int* sidx;        // or null = classic records in `sorted`
+    const double* src;      // water i of frame f at src + f * src_fstride + i * src_astride
+    int64_t src_fstride, src_astride;
 };
+
+// where the certification and the exact search get a water's fp64 coordinates from: the sorted records (REC = double4 /
+// float4), or -- index records -- the source frame through the original index
+template <class REC> struct wol_rec_src {
+    const REC* p;
+    __device__ __forceinline__ double4 by_slot(int j) const { return wol_rec<REC>::wide(p[j]); }
+    __device__ __forceinline__ double4 by_prop(int j) const { return wol_rec<REC>::wide(p[j]); }   // (proposals name slots)
+};
+struct wol_idx_src {
+    const int* sidx;      // of the frame
+    const double* rows;   // of the frame
+    int64_t astride;
+    __device__ __forceinline__ double4 by_prop(int idx) const {   // (proposals name original indices)
+        const double* q = rows + astride * (int64_t)idx;
+        double4 v;
+        v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = __longlong_as_double((long long)idx);
+        return v;
+    }
+    __device__ __forceinline__ double4 by_slot(int j) const { return by_prop(sidx[j]); }
+};
+template <class REC, bool IDX> struct wol_src_of { typedef wol_rec_src<REC> type; };
+template <class REC> struct wol_src_of<REC, true> { typedef wol_idx_src type; };
+template <class REC, bool IDX, class ARGS>
+__device__ __forceinline__ typename wol_src_of<REC, IDX>::type wol_frame_src(const ARGS& a, int f) {
+    if constexpr (IDX) return wol_idx_src{a.sidx + (int64_t)f * a.n, a.src + (int64_t)f * a.src_fstride, a.src_astride};
+    else return wol_rec_src<REC>{reinterpret_cast<const REC*>(a.sorted) + (int64_t)f * a.n};
+}
 
 // sorted insert of `key` into k0 <= k1 <= ... <= k4 (the largest falls off): new k_i is the median of
 // (old k_{i-1}, old k_i, key).  Done from the top down so every op still sees the old lower
@@ -718,7 +750,7 @@ __device__ __forceinline__ bool wol_lean_water(const FastArgs& a, const FrameGri
 #ifndef WOL_FINISH_WPS
 #define WOL_FINISH_WPS 4
 #endif
-template <bool LEAN, class REC = double4>
+template <bool LEAN, class REC = double4, bool IDX = false>
 __global__ void __launch_bounds__(WOL_BLOCK, WOL_FINISH_WPS)
 k_finish_fast(FastArgs a) {
     extern __shared__ int lds_hist[];
@@ -743,7 +775,7 @@ k_finish_fast(FastArgs a) {
     long long sum_h = 0, sum_l = 0, sum_h2 = 0, sum_l2 = 0;  // this lane's share of frame f's sums of q, q^2
     const FrameGrid& g = a.grids[f];
     if (g.maxshell < 0) continue;  // all-pairs frame
-    const REC* __restrict__ sp = reinterpret_cast<const REC*>(a.sorted) + (int64_t)f * a.n;
+    const auto sp = wol_frame_src<REC, IDX>(a, f);
     const int eps_u = a.rows ? g.row_eps_units : g.eps_units;
     for (int s0 = kb * WOL_BLOCK; s0 < a.n; s0 += KB * WOL_BLOCK) {  // uniform bounds: whole waves stay in the loop
         const int s = min(s0 + (int)threadIdx.x, a.n - 1);
@@ -753,7 +785,7 @@ k_finish_fast(FastArgs a) {
         // (fetching the next 256 waters' share ahead of time was measured: no change, the gathers are what costs)
         const int kd3 = live ? a.prop_key[w] : 0;
         const int4 pr_all = a.prop[w];
-        const double4 mev_all = wol_rec_load(sp, s);
+        const double4 mev_all = sp.by_slot(s);
         bool slow = live && kd3 < 0;
         long long acc_h = 0, acc_l = 0, acc_h2 = 0, acc_l2 = 0;  // this water's share of the frame sums
         if constexpr (LEAN) { if (live && !slow) {
@@ -764,10 +796,10 @@ k_finish_fast(FastArgs a) {
             const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
 #ifdef WOL_EXP_FINISH_COALESCED   // ablation build: timing only, results are wrong (neighbours = the next four slots)
-            const double4 nb[4] = {wol_rec_load(sp, min(s + 1 + (pr.x & 0), a.n - 1)), wol_rec_load(sp, min(s + 2 + (pr.y & 0), a.n - 1)),
-                                   wol_rec_load(sp, min(s + 3 + (pr.z & 0), a.n - 1)), wol_rec_load(sp, min(s + 4 + (pr.w & 0), a.n - 1))};
+            const double4 nb[4] = {sp.by_slot(min(s + 1 + (pr.x & 0), a.n - 1)), sp.by_slot(min(s + 2 + (pr.y & 0), a.n - 1)),
+                                   sp.by_slot(min(s + 3 + (pr.z & 0), a.n - 1)), sp.by_slot(min(s + 4 + (pr.w & 0), a.n - 1))};
 #else
-            const double4 nb[4] = {wol_rec_load(sp, pr.x), wol_rec_load(sp, pr.y), wol_rec_load(sp, pr.z), wol_rec_load(sp, pr.w)};
+            const double4 nb[4] = {sp.by_prop(pr.x), sp.by_prop(pr.y), sp.by_prop(pr.z), sp.by_prop(pr.w)};
 #endif
             const double nbx[4] = {nb[0].x, nb[1].x, nb[2].x, nb[3].x}, nby[4] = {nb[0].y, nb[1].y, nb[2].y, nb[3].y},
                          nbz[4] = {nb[0].z, nb[1].z, nb[2].z, nb[3].z};
@@ -777,7 +809,7 @@ k_finish_fast(FastArgs a) {
             const int4 pr = pr_all;
             const double4 mev = mev_all;
             const double c[3] = {mev.x, mev.y, mev.z};
-            const double4 n0 = wol_rec_load(sp, pr.x), n1 = wol_rec_load(sp, pr.y), n2 = wol_rec_load(sp, pr.z), n3 = wol_rec_load(sp, pr.w);
+            const double4 n0 = sp.by_prop(pr.x), n1 = sp.by_prop(pr.y), n2 = sp.by_prop(pr.z), n3 = sp.by_prop(pr.w);
             Top4 t;
             top4_init(t);
             double dist;
@@ -895,7 +927,7 @@ __device__ __forceinline__ void wol_top4_wave_merge(Top4& t) {
     }
 }
 
-template <class REC>   // storage form of the sorted records (wol_rec: double4, or float4 for float32 frames)
+template <class REC, bool IDX = false>   // storage form of the sorted records (wol_rec: double4, or float4 for float32 frames; IDX: none)
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_list,
                     const int* __restrict__ slow_count) {
@@ -913,9 +945,9 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
         const unsigned long long e = slow_list[i];
         const int f = (int)(e >> 32), s = (int)(e & 0xFFFFFFFFu);
         const FrameGrid& g = a.grids[f];
-        const REC* __restrict__ sp = reinterpret_cast<const REC*>(a.sorted) + (int64_t)f * a.n;
+        const auto sp = wol_frame_src<REC, IDX>(a, f);
         const int* __restrict__ cs = a.cell_start + g.cell_base;
-        const double4 v = wol_rec_load(sp, s);
+        const double4 v = sp.by_slot(s);
         const double c[3] = {v.x, v.y, v.z};
         double fr[3];
         int cc[3];
@@ -947,7 +979,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
                 const int cell = (cz * g.nc[1] + cy) * g.nc[0] + cx;
                 const int b = cs[cell], en = cs[cell + 1];
                 for (int j = b; j < en; ++j) {
-                    const double4 p = wol_rec_load(sp, j);
+                    const double4 p = sp.by_slot(j);
                     double dist;
                     bool in_mask;
                     if (wol_eval_pair(c, p.x, p.y, p.z, g.box, a.lowsq, a.highsq, mine.bound2, &dist, &in_mask))
@@ -967,7 +999,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
             if (all.n == 4 && all.d3 <= rg) break;
         }
         if (lane == 0) {
-            const double4 n0 = wol_rec_load(sp, all.s0), n1 = wol_rec_load(sp, all.s1), n2 = wol_rec_load(sp, all.s2), n3 = wol_rec_load(sp, all.s3);
+            const double4 n0 = sp.by_slot(all.s0), n1 = sp.by_slot(all.s1), n2 = sp.by_slot(all.s2), n3 = sp.by_slot(all.s3);
             const double N0[3] = {n0.x, n0.y, n0.z}, N1[3] = {n1.x, n1.y, n1.z};
             const double N2[3] = {n2.x, n2.y, n2.z}, N3[3] = {n3.x, n3.y, n3.z};
             wol_finish_water(c, all, N0, N1, N2, N3, g.box, a.out, (int64_t)f * a.ns + (int)__double_as_longlong(v.w),

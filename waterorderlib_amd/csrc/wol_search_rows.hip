@@ -380,12 +380,15 @@ k_search_rows(FastArgs a) {
             while (r < nrows) { WOL_ROW_PARAMS(r); if (cnt > 0) break; r += NW; }   // first non-empty row of this wave
             float4 vn;
             vn.x = vn.y = vn.z = vn.w = 0.f;
+            // (index records: the id word names the water's ORIGINAL index, fetched with its record)
+            const int* __restrict__ sidx = a.sidx ? a.sidx + frame_off : nullptr;
+            int idn = 0;
             int srcn = lane + (lane < c0 ? d0 : lane >= c0 + c1 ? d2 : d1);
-            if (r < nrows && lane < cnt) vn = sp32[srcn];
+            if (r < nrows && lane < cnt) { vn = sp32[srcn]; idn = sidx ? sidx[srcn] : srcn; }
             while (r < nrows) {
                 // the current chunk of 64 waters
                 const float4 v = vn;
-                const int src = srcn, i = i0 + lane;
+                const int src = idn, i = i0 + lane;
                 const int cc0 = c0, cc1 = c1, ccnt = cnt, ctb = tb, cbin = binbase, cob = obbase;
                 const float coffy = offy, coffz = offz;
                 // advance to the next chunk and start its fetch
@@ -397,7 +400,7 @@ k_search_rows(FastArgs a) {
                 if (r < nrows) {
                     const int in_ = i0 + lane;
                     srcn = in_ + (in_ < c0 ? d0 : in_ >= c0 + c1 ? d2 : d1);
-                    if (in_ < cnt) vn = sp32[srcn];
+                    if (in_ < cnt) { vn = sp32[srcn]; idn = sidx ? sidx[srcn] : srcn; }
                 }
                 // place the current chunk
                 if (i < ccnt) {
