@@ -23,6 +23,8 @@ for seed in range(first, first + count):
     for rows in (1, 0):
         for dev in (False, True):
             c = _lib.Context(0); c.set_option("search_rows", rows)
+            for kv in os.environ.get("WOL_SOAK_OPTIONS", "").split(","):   # e.g. WOL_SOAK_OPTIONS=idx_sort=1,seg_sort=2
+                if "=" in kv: c.set_option(kv.split("=")[0], float(kv.split("=")[1]))
             src = torch.from_numpy(frames).cuda() if dev else frames
             r = engine.tet_order_traj(src, boxes, lowCut=lo, highCut=hi, len_wat=len_wat, want_q=want_q, ctx=c)
             g = (lambda a: a.cpu().numpy()) if dev else (lambda a: a)
