@@ -898,8 +898,9 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                     tile_any = S.tile_any.as<int>();
                     bp->tile_any_stride = nrow_max + 1;
                 }
-                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, c->grid_stream, S.grids.as<FrameGrid>(), S.cells.as<int>(),
-                                   c->layer_off.as<int>(), ro_stride, S.level.as<int>(), tile_any, nrow_max + 1);
+                const int rows_cap = std::min(nrow_max, 12288);   // (frames with more rows keep the densest level: 48 KB of LDS at most)
+                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), sizeof(int) * (size_t)rows_cap, c->grid_stream, S.grids.as<FrameGrid>(), S.cells.as<int>(),
+                                   c->layer_off.as<int>(), ro_stride, S.level.as<int>(), tile_any, nrow_max + 1, rows_cap);
                 HIP_TRY(hipEventRecord(S.level_ev, c->grid_stream));
                 level_early = true;
             }
@@ -999,8 +1000,11 @@ int run_q_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_
             }
             if (!level_early) {
                 WOL_TRY(S.level.ensure(sizeof(int) * (size_t)F));
-                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), 0, qs, a.grids, a.cell_start, (const int*)nullptr, 0, S.level.as<int>(),
-                                   (int*)nullptr, 0);
+                int nrow_all = 1;
+                for (int f = 0; f < F; ++f) if (bp.gh[f].maxshell >= 0) nrow_all = std::max(nrow_all, bp.gh[f].nc[1] * bp.gh[f].nc[2]);
+                const int rows_cap = std::min(nrow_all, 12288);
+                hipLaunchKernelGGL(k_pick_level, dim3(F), dim3(WOL_BLOCK), sizeof(int) * (size_t)rows_cap, qs, a.grids, a.cell_start, (const int*)nullptr, 0, S.level.as<int>(),
+                                   (int*)nullptr, 0, rows_cap);
             }
             FastArgs fa;
             fa.level = S.level.as<int>();

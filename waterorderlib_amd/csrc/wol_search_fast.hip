@@ -245,14 +245,15 @@ __device__ __forceinline__ void wol_finish_water_fastq(const double a[3], const 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(WOL_BLOCK)
 k_pick_level(const FrameGrid* __restrict__ grids, const int* __restrict__ cell_start, const int* __restrict__ row_off,
-             int ro_stride, int* __restrict__ level, int* __restrict__ tile_any, int tile_any_stride) {
-    __shared__ int rows[12288];
+             int ro_stride, int* __restrict__ level, int* __restrict__ tile_any, int tile_any_stride, int rows_cap) {
+    extern __shared__ int rows[];     // [rows_cap] waters per cell row (dynamic: small frames come in batches of thousands, and
+                                      // the kernel runs beside the second sort level -- a block must not hold 48 KB for 81 rows)
     __shared__ int smax[WOL_BLOCK];
     const int f = blockIdx.x, tid = threadIdx.x;
     const FrameGrid& g = grids[f];
     const int nx = g.nc[0], ny = g.nc[1], nz = g.nc[2], nrow = ny * nz;
     const int* __restrict__ cs = cell_start + g.cell_base;
-    const bool ok = g.maxshell >= 0 && nrow <= 12288;
+    const bool ok = g.maxshell >= 0 && nrow <= rows_cap;
     // waters per (z, y) cell row: from the first sort level's row offsets where it ran (the kernel then runs beside the
     // second level), else from the finished cell table
     if (ok && row_off) {
