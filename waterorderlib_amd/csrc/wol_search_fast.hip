@@ -906,15 +906,18 @@ k_finish_fast(FastArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// kernel 3: exact search for the waters the filter could not certify -- ONE WAVE PER WATER.
-// The cells of each shell are dealt to the 64 lanes (a lane-serial walk is a chain of dependent
+// kernel 3: exact search for the waters the filter could not certify -- HALF A WAVE PER WATER (the 27 cells of the first
+// shells fit 32 lanes; at 151 VGPRs three waves per SIMD are resident, and a 100 000-water batch's ~5 000 listed waters
+// then need one pass of the resident waves instead of two).
+// The cells of each shell are dealt to the 32 lanes (a lane-serial walk is a chain of dependent
 // L2 round trips); every lane ranks its cells' candidates with the exact arithmetic into its own
 // top-4, a butterfly of sorted-list merges gives all lanes the wave-wide top-4, and the shell loop
 // ends under the same guarantee as wol_search_exact_one.
 // ---------------------------------------------------------------------------------------------
+template <int FIRST = 32>   // 32: over the whole wave; 16: inside each half of it (two waters per wave)
 __device__ __forceinline__ void wol_top4_wave_merge(Top4& t) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = FIRST; off >= 1; off >>= 1) {
         const double od0 = __shfl_xor(t.d0, off, 64), od1 = __shfl_xor(t.d1, off, 64);
         const double od2 = __shfl_xor(t.d2, off, 64), od3 = __shfl_xor(t.d3, off, 64);
         const int oj0 = __shfl_xor(t.j0, off, 64), oj1 = __shfl_xor(t.j1, off, 64);
@@ -939,9 +942,9 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
     if (lds_dh) wol_hist_zero(lds_dh, a.out.dbins);
     __syncthreads();
     const int count = *slow_count;
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * WOL_BLOCK + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * WOL_BLOCK) >> 6;
+    const int lane = threadIdx.x & 31;                                  // lane inside the half wave
+    const int wave = (blockIdx.x * WOL_BLOCK + threadIdx.x) >> 5;       // half-wave number
+    const int nwaves = (gridDim.x * WOL_BLOCK) >> 5;
     for (int i = wave; i < count; i += nwaves) {
         const unsigned long long e = slow_list[i];
         const int f = (int)(e >> 32), s = (int)(e & 0xFFFFFFFFu);
@@ -964,7 +967,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
             const int w = 2 * shell + 1;
             const float inv_w = 1.0f / (float)w;
             const int ncube = w * w * w;
-            for (int idx = lane; idx < ncube; idx += 64) {
+            for (int idx = lane; idx < ncube; idx += 32) {
                 const int iz = (int)(((float)idx + 0.5f) * inv_w * inv_w);
                 const int rem = idx - iz * w * w;
                 const int iy = (int)(((float)rem + 0.5f) * inv_w);
@@ -988,7 +991,7 @@ k_search_exact_list(SearchArgs a, const unsigned long long* __restrict__ slow_li
                 }
             }
             all = mine;
-            wol_top4_wave_merge(all);
+            wol_top4_wave_merge<16>(all);
             double rg = __builtin_huge_val();
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
