@@ -49,6 +49,19 @@ struct FrameGrid {
     int eps_units;      // bound on |fp32 key - exact d^2 * S|
 };
 
+// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (shifts inside the rows of 16, then the row totals
+// broadcast to the rows behind) where a __shfl_up step is a ds_bpermute, i.e. one more instruction for the LDS unit the
+// sweeps of the other blocks are reading their candidates through
+__device__ __forceinline__ int wol_wave_scan_incl(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // A water in the cell-sorted arrays: (x, y, z, original index).  Two storage forms: double4 (index as the bits of .w) and,
 // for frames stored as float32, float4 -- single-precision values are carried as they are (16 bytes instead of 32 through
 // both sort levels and in the certification kernel's gathers) and promoted, exactly, where the fp64 arithmetic starts.

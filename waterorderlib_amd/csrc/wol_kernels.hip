@@ -62,12 +62,7 @@ k_cell_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cell_count) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = (i + u < ncell) ? c[i + u] : 0;
         const int s = (v[0] + v[1]) + (v[2] + v[3]);
-        int inc = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int x = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += x;
-        }
+        const int inc = wol_wave_scan_incl(s);
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
         int before = 0, total = 0;
@@ -97,12 +92,7 @@ k_cell_scan_tiles(const FrameGrid* __restrict__ grids, int* __restrict__ cell_co
 #pragma unroll
     for (int u = 0; u < 4; ++u) v[u] = (i + u < ncell) ? c[i + u] : 0;
     const int s = (v[0] + v[1]) + (v[2] + v[3]);
-    int inc = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int x = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += x;
-    }
+    const int inc = wol_wave_scan_incl(s);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     int before = 0, total = 0;
@@ -122,12 +112,7 @@ k_cell_scan_totals(const FrameGrid* __restrict__ grids, int* __restrict__ cell_c
     const int ntile = (g.ncell + 4095) / 4096;   // <= 1024 tiles: 4 M cells
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v = tid < ntile ? tt[tid] : 0;
-    int inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int x = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += x;
-    }
+    const int inc = wol_wave_scan_incl(v);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
     int before = 0, total = 0;
@@ -375,12 +360,7 @@ __device__ __forceinline__ void wol_sort_rows_chunks(const T* __restrict__ base,
         // (2) starts of the rows inside the chunk (thread t owns rows [sb, se)); cursors advance by the chunk's counts
         int s2 = 0;
         for (int k = sb; k < se; ++k) s2 += icnt[k];
-        int inc = s2;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += v;
-        }
+        const int inc = wol_wave_scan_incl(s2);
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
         int before = 0;
@@ -551,12 +531,7 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
         // for the second level; the row totals advance
         int s2 = 0;
         for (int k = sb; k < se; ++k) s2 += icnt[k];
-        int inc = s2;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += v;
-        }
+        const int inc = wol_wave_scan_incl(s2);
         if (lane == 63) wtot[wave] = inc;
         __syncthreads();
         int before = 0;
@@ -787,17 +762,12 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
                 const int c = c0 + lane;
                 const int t0 = c < nchunk ? (int)tabl[c * (ny + 1) + cy] : 0;
                 const int len = c < nchunk ? (int)tabl[c * (ny + 1) + cy + 1] - t0 : 0;
-                int inc = len;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int t = __shfl_up(inc, off, 64);
-                    if (lane >= off) inc += t;
-                }
+                const int inc = wol_wave_scan_incl(len);
                 if (c < nchunk) {
                     cpre[c] = run + inc - len;
                     csrc[c] = c * rp.chunk_waters + t0 - (run + inc - len);
                 }
-                run += __shfl(inc, 63, 64);
+                run += __builtin_amdgcn_readlane(inc, 63);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -884,12 +854,7 @@ k_sort_in_row(const FrameGrid* __restrict__ grids, const int* __restrict__ row_o
                     c[k][j] = (k < cpl && cell < nx) ? cnt[cell * WOL_XSUB + j] : 0;
                     s += c[k][j];
                 }
-            int inc = s;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int t = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += t;
-            }
+            const int inc = wol_wave_scan_incl(s);
             int run = inc - s;
             __builtin_amdgcn_wave_barrier();
 #pragma unroll

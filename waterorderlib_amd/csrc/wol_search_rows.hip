@@ -58,19 +58,6 @@
 #define WOL_ROWS_WPS 6         // 80 VGPRs at most: three blocks (24 waves) per CU
 #endif
 
-// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (shifts inside the rows of 16, then the row totals
-// broadcast to the rows behind) where a __shfl_up step is a ds_bpermute, i.e. one more instruction for the LDS unit the
-// sweeps of the other blocks are reading their candidates through
-__device__ __forceinline__ int wol_wave_scan_incl(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
 // one candidate pair against the lane's water: two keys = squared distance in key units << 12 | entry number.
 // Coordinates are staged in units of sqrt(2^-20 key range), so d^2 comes out in [0, 1] and saturates through the CLAMP
 // modifier of its last fma; one more packed fma (x (2^20 - 1) + 2^23) turns it into the float whose mantissa IS the
