@@ -757,6 +757,9 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows<float, WOL_SORT_BLOCK, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
                 HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG, float4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+                // (16-byte records: chunks twice as long fit beside the big row tables)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sort_rows_scatter<float, 2 * WOL_L1_CHUNK_BIG, float4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)wol_sort_rows_lds(WOL_L1_MAXROWS_BIG, 2 * WOL_L1_CHUNK_BIG, WOL_SORT_BLOCK, sizeof(float4))));
                 c->sort_rows_lds_set = 1;
             }
             // (chunks of the split single-pass form below: smaller where the row tables are big)
@@ -868,8 +871,8 @@ int sort_batch(wol_ctx* c, const FramesView<T>& fv, int F, const double* boxes_h
                                    c->layer_off.as<int>(), ro_stride);
                 if constexpr (std::is_same<T, float>::value) {
                     if (rec32 && big_rows)
-                        hipLaunchKernelGGL((k_sort_rows_scatter<float, WOL_L1_CHUNK_BIG, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK),
-                                           wol_sort_rows_lds(nrow_max, WOL_L1_CHUNK_BIG, WOL_SORT_BLOCK, rec_size), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
+                        hipLaunchKernelGGL((k_sort_rows_scatter<float, 2 * WOL_L1_CHUNK_BIG, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK),
+                                           wol_sort_rows_lds(nrow_max, 2 * WOL_L1_CHUNK_BIG, WOL_SORT_BLOCK, rec_size), ss, fv, S.grids.as<FrameGrid>(), cntb, ro_stride, P,
                                            c->sort_tmp.as<float4>(), nrow_max);
                     else if (rec32)
                         hipLaunchKernelGGL((k_sort_rows_scatter<float, WOL_L1_CHUNK, float4>), dim3(P, F), dim3(WOL_SORT_BLOCK),
