@@ -62,6 +62,21 @@ __device__ __forceinline__ int wol_wave_scan_incl(int v) {
     return v;
 }
 
+// part[tid] <- inclusive prefix of s over the threads of the block (whole waves): the waves scan in DPP, their totals are
+// combined through the first entries of part[] -- four barriers where a Hillis-Steele scan in LDS takes two per doubling
+__device__ __forceinline__ void wol_block_scan_incl(int s, int* part) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int inc = wol_wave_scan_incl(s);
+    __syncthreads();
+    if (lane == 63) part[wave] = inc;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += part[w];
+    __syncthreads();
+    part[tid] = before + inc;
+    __syncthreads();
+}
+
 // A water in the cell-sorted arrays: (x, y, z, original index).  Two storage forms: double4 (index as the bits of .w) and,
 // for frames stored as float32, float4 -- single-precision values are carried as they are (16 bytes instead of 32 through
 // both sort levels and in the certification kernel's gathers) and promoted, exactly, where the fp64 arithmetic starts.

@@ -218,14 +218,7 @@ k_sort_frame_lds(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __r
     const int b = min(tid * per, ncell), e = min(b + per, ncell);
     int s = 0;
     for (int k = b; k < e; ++k) s += cnt[k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
-        const int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
+    wol_block_scan_incl(s, part);   // part[tid] = inclusive prefix over the block's threads
     int run = part[tid] - s;
     for (int k = b; k < e; ++k) { const int v = cnt[k]; cnt[k] = run; run += v; }
     if (tid == WOL_SORT_BLOCK - 1) cnt[ncell] = part[WOL_SORT_BLOCK - 1];
@@ -447,14 +440,7 @@ k_sort_rows(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __restri
     const int sb = min(tid * per, nrow), se = min(sb + per, nrow);
     int s = 0;
     for (int k = sb; k < se; ++k) s += cnt[k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < SB; off <<= 1) {
-        const int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
+    wol_block_scan_incl(s, part);   // part[tid] = inclusive prefix over the block's threads
     int* ro = row_off + (int64_t)f * ro_stride;
     int run = part[tid] - s;
     for (int k = sb; k < se; ++k) { const int v = cnt[k]; cnt[k] = run; ro[k] = run; run += v; }
@@ -587,14 +573,7 @@ k_sort_rows_seg(FramesView<T> fv, const FrameGrid* __restrict__ grids, int* __re
     // exclusive scan of the row totals: the rows' places in the final arrays
     int s = 0;
     for (int k = sb; k < se; ++k) s += tot[k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < SB; off <<= 1) {
-        const int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
+    wol_block_scan_incl(s, part);   // part[tid] = inclusive prefix over the block's threads
     int* ro = row_off + (int64_t)f * ro_stride;
     int run = part[tid] - s;
     for (int k = sb; k < se; ++k) { ro[k] = run; run += tot[k]; }
@@ -634,14 +613,7 @@ k_sort_rows_scan(const FrameGrid* __restrict__ grids, int* __restrict__ cntb, in
     int s = 0;
     for (int k = sb; k < se; ++k)
         for (int p = 0; p < P; ++p) s += cb[(int64_t)p * stride + k];
-    part[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < WOL_SORT_BLOCK; off <<= 1) {
-        const int v = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
+    wol_block_scan_incl(s, part);   // part[tid] = inclusive prefix over the block's threads
     int* ro = row_off + (int64_t)f * ro_stride;
     int run = part[tid] - s;
     for (int k = sb; k < se; ++k) {
