@@ -267,7 +267,9 @@ k_search_rows(FastArgs a) {
             rcnt[3 * tid + 2] = (unsigned short)min(er - sr, 65535);
         }
         {
-            constexpr int W0 = (WOL_ROWS_MAXROWS + 63) / 64;     // waves the row table keeps busy
+            // (the row table above keeps (nrows + 63) / 64 waves busy -- one, for tiles of up to 19 rows: the other seven then
+            //  take one triple each on the benchmark box's 32 x 5-cell tiles, where six waves had one of them do two in turn)
+            const int W0 = (nrows + 63) >> 6;
             const int ncs = sxe + 2;                             // staged cells of a row (<= 63: one lane each)
             for (int t = wave - W0; t >= 0 && t < ntrip; t += NW - W0) {
                 unsigned w0 = 0u, w1 = 0u, w2 = 0u;
